@@ -1,0 +1,30 @@
+# Top-level build: libptgpu.so (HIP, gfx950), libpthost.so + pt (C++ host), oracle (test infrastructure).
+HIPCC ?= /opt/rocm/bin/hipcc
+CXX ?= g++
+PKG = path-tracer_amd
+LIB = $(PKG)/lib
+# -ffp-contract=off: hit records must be bit-identical to the CPU restatement; fma only where written.
+HIPFLAGS = -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -munsafe-fp-atomics -fPIC -Wall -Wno-unused-function
+CSRC = $(PKG)/csrc
+GPU_DEPS = $(wildcard $(CSRC)/*.h $(CSRC)/*.inc) include/ptgpu.h
+
+all: $(LIB)/libptgpu.so $(LIB)/libpthost.so $(LIB)/pt oracle
+
+$(LIB)/libptgpu.so: $(CSRC)/ptgpu.hip $(CSRC)/bvh_build.cpp $(CSRC)/sdtree_host.cpp $(GPU_DEPS)
+	mkdir -p $(LIB)
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/ptgpu.hip $(CSRC)/bvh_build.cpp $(CSRC)/sdtree_host.cpp
+
+$(LIB)/libpthost.so: $(PKG)/host/pthost.cpp include/pthost.h include/ptgpu.h $(CSRC)/cie_data.inc
+	mkdir -p $(LIB)
+	$(CXX) -O2 -std=c++17 -fPIC -ffp-contract=off -Wall -shared -o $@ $(PKG)/host/pthost.cpp -ldl
+
+$(LIB)/pt: $(PKG)/host/pt_main.cpp $(LIB)/libpthost.so $(LIB)/libptgpu.so
+	$(CXX) -O2 -std=c++17 -Wall -o $@ $(PKG)/host/pt_main.cpp -L$(LIB) -lpthost -lptgpu -Wl,-rpath,'$$ORIGIN'
+
+oracle:
+	$(MAKE) -C oracle
+
+clean:
+	rm -rf $(LIB) oracle/_build
+
+.PHONY: all oracle clean

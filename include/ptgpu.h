@@ -1,0 +1,172 @@
+/* ptgpu.h — C ABI of the MI355X wavefront path tracer (libptgpu.so).
+ *
+ * Drop-in boundary for the hot path of eDev03/Path-tracer's `pt` crate: everything below
+ * `Integrator::render(&mut self, scene, spp, camera, film)` (pt/src/integrator/mod.rs:34-46), i.e. the
+ * per-sample loops of the `path`, `lightpath` and `guided` integrators and all they call.
+ * The reference has no FFI; these entry points are what an `extern "C"` block in a thin Rust FFI crate
+ * would bind (see INTEGRATION.md for the Rust side). Plain pointers and sizes only; the caller owns every
+ * host buffer; the library copies what it needs during the call. All functions return 0 on success or a
+ * negative PTGPU_E_* code and never throw/abort across the ABI; ptgpu_last_error() gives the message.
+ * One context = one GPU; a context is not re-entrant (one call at a time), calls block until done.
+ */
+#ifndef PTGPU_H
+#define PTGPU_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PTGPU_OK 0
+#define PTGPU_E_INVALID (-1)  /* bad argument / inconsistent description */
+#define PTGPU_E_DEVICE (-2)   /* HIP runtime error (no GPU, out of memory, launch failure) */
+#define PTGPU_E_STATE (-3)    /* call order (e.g. render before scene_create / camera_set) */
+#define PTGPU_E_LIMIT (-4)    /* a documented limit was exceeded (e.g. DTree > 65535 nodes) */
+
+typedef struct ptgpu_ctx ptgpu_ctx;
+
+/* Sigmoid-polynomial spectrum = the reference's TristimulusSpectrum after construction
+ * (pt/src/spectrum/mod.rs:262-335): s(l) = scale * (0.5 + x / (2 sqrt(1 + x^2))), x = fma(l, fma(l,c0,c1), c2).
+ * The host keeps `Spectrum::new` / rgb2spec::fetch_coeffs (scene-build time) and passes the result. */
+typedef struct ptgpu_spectrum {
+    float c0, c1, c2, scale;
+} ptgpu_spectrum;
+
+/* io_bridge::Material (pt/src/io_bridge.rs) / scene::Material (pt/src/scene.rs:21-33). */
+enum { PTGPU_MAT_LAMBERTIAN = 0, PTGPU_MAT_DIELECTRIC = 1, PTGPU_MAT_CONDUCTOR = 2 };
+typedef struct ptgpu_material {
+    int32_t kind;      /* PTGPU_MAT_* */
+    float roughness;   /* conductor alpha */
+    ptgpu_spectrum s0; /* albedo | eta */
+    ptgpu_spectrum s1; /* conductor k */
+} ptgpu_material;
+
+/* io_bridge::Mesh (pt/src/io_bridge.rs), world-space, as handed to Scene::new (pt/src/scene.rs:89-93). */
+typedef struct ptgpu_mesh {
+    const float* points;       /* n_points * 3 */
+    const float* normals;      /* n_points * 3, or NULL = flat shaded (empty `normals`) */
+    const uint32_t* triangles; /* n_triangles * 3 vertex indices */
+    uint32_t n_points;
+    uint32_t n_triangles;
+    int32_t material_index;  /* index into materials, -1 = None (pass-through surface) */
+    int32_t emissive;        /* != 0 <=> io_bridge emission != RGB 0 */
+    ptgpu_spectrum emission; /* illuminant spectrum (multiplied by D65 on evaluation) */
+} ptgpu_mesh;
+
+typedef struct ptgpu_scene_desc {
+    const ptgpu_mesh* meshes;
+    const ptgpu_material* materials;
+    uint32_t n_meshes;
+    uint32_t n_materials;
+} ptgpu_scene_desc;
+
+/* io_bridge::CameraOptions (pt/src/io_bridge.rs) -> Camera::new (pt/src/camera.rs:33-41). */
+typedef struct ptgpu_camera_desc {
+    float world_to_camera[16]; /* row-major 4x4 */
+    float fov_deg;             /* vertical field of view */
+    uint32_t resx, resy;
+} ptgpu_camera_desc;
+
+/* io_bridge::Integrator (pt/src/io_bridge.rs) -> Integrator::new (pt/src/integrator/mod.rs:21-33). */
+enum { PTGPU_INTEGRATOR_LIGHTPATH = 0, PTGPU_INTEGRATOR_PATH = 1, PTGPU_INTEGRATOR_GUIDED = 2 };
+enum { PTGPU_MODE_PT = 0, PTGPU_MODE_NEE = 1, PTGPU_MODE_MIS = 2 };
+enum { PTGPU_FILTER_NEAREST = 0, PTGPU_FILTER_BOX = 1, PTGPU_FILTER_STOCHASTIC = 2 };
+typedef struct ptgpu_integrator_desc {
+    int32_t kind;                /* PTGPU_INTEGRATOR_* */
+    uint32_t max_depth;
+    int32_t mode;                /* PTGPU_MODE_* (path, guided) */
+    float spatial_threshold;     /* guided: `spatial_threashold` */
+    float directional_threshold; /* guided: carried for fidelity; render uses 0.01 like path_guiding/mod.rs:73 */
+    int32_t spatial_filter;      /* guided: only STOCHASTIC (and NEAREST) supported = what the parser can select */
+    int32_t directional_filter;  /* guided: only BOX (and NEAREST) supported */
+} ptgpu_integrator_desc;
+
+/* Counters filled by ptgpu_render*. Times are host wall-clock around the device work of the call. */
+typedef struct ptgpu_stats {
+    uint64_t samples;        /* camera / light paths started */
+    uint64_t extend_rays;    /* closest-hit rays traced */
+    uint64_t shadow_rays;    /* occlusion rays traced */
+    uint64_t segments;       /* shaded surface interactions */
+    uint64_t kernel_launches;
+    double render_ms;        /* whole call */
+    double extend_ms;        /* sum of HIP-event times of extend launches (0 unless profiling enabled) */
+    double shade_ms;
+    uint64_t stree_nodes;    /* guided: final spatial tree size */
+    uint64_t dtree_nodes;    /* guided: total directional nodes over leaves */
+} ptgpu_stats;
+
+typedef struct ptgpu_hit {
+    uint32_t mesh_index;     /* CompactTriangle (pt/src/bvh.rs:18-22) after Scene::new's emissive-first reordering */
+    uint32_t triangle_index;
+    uint32_t leaf_index;     /* position in Bvh::compact_triangles (leaf order) */
+    uint32_t hit;            /* 1 = hit, 0 = miss (other fields zero) */
+    float t, b0, b1, b2;     /* RayTriangleIntersection (pt/src/geom.rs:68-73) */
+} ptgpu_hit;
+
+const char* ptgpu_last_error(void);
+
+/* Create a context on HIP device `device_id`. */
+int ptgpu_init(ptgpu_ctx** out, int device_id);
+void ptgpu_destroy(ptgpu_ctx* ctx);
+
+/* Replaces Scene::new (pt/src/scene.rs:89-183) + Bvh::new (pt/src/bvh.rs:48-85): emissive-first mesh
+ * ordering, 12-bucket SAH build on the host (bit-identical leaf order), flattening to HBM. */
+int ptgpu_scene_create(ptgpu_ctx* ctx, const ptgpu_scene_desc* desc);
+/* Replaces Camera::new + Film::new (pt/src/camera.rs:33-41,150-160). */
+int ptgpu_camera_set(ptgpu_ctx* ctx, const ptgpu_camera_desc* cam);
+
+/* Replaces Integrator::render + Film::create_pixels(1.0) + Integrator::film_scale
+ * (pt/src/integrator/mod.rs:34-55, pt/src/camera.rs:184-196).
+ * film_rgb_out: resx*resy*3 doubles, row-major (x + y*resx), UNSCALED sums of tile pixels + splats;
+ * film_scale_out: the factor save_image would apply. stats may be NULL. */
+int ptgpu_render(ptgpu_ctx* ctx, const ptgpu_integrator_desc* integrator, uint32_t spp, double* film_rgb_out,
+                 double* film_scale_out, ptgpu_stats* stats);
+
+/* Same, for one shard of a multi-GPU job: this context renders only the sample indices i with
+ * i % shard_count == shard_index (path, lightpath), or those sample passes of every guided wave. The caller
+ * sums the shards' films (and, for guided, all-reduces the statistics buffer between waves, below). */
+int ptgpu_render_shard(ptgpu_ctx* ctx, const ptgpu_integrator_desc* integrator, uint32_t spp, uint32_t shard_index,
+                       uint32_t shard_count, double* film_rgb_out, double* film_scale_out, ptgpu_stats* stats);
+
+/* Guided integrator, wave by wave (PathGuidingIntegrator::render, pt/src/integrator/path_guiding/mod.rs:70-122)
+ * so that a multi-GPU driver can all-reduce the SD-tree statistics between waves:
+ *   begin -> for w in 0..n_waves { wave(w); [all-reduce stats in place]; } -> end.
+ * ptgpu_guided_stats returns the DEVICE pointer and element count (f32) of the flat collector buffer of the
+ * wave just traced: per spatial leaf its DTree node sums (4 per node) followed by one statistical weight.
+ * Topology is identical on every shard, so an element-wise sum across GPUs is exactly the single-GPU state
+ * up to f32 reassociation. */
+int ptgpu_guided_begin(ptgpu_ctx* ctx, const ptgpu_integrator_desc* integrator, uint32_t spp, uint32_t shard_index,
+                       uint32_t shard_count, uint32_t* n_waves_out);
+int ptgpu_guided_wave(ptgpu_ctx* ctx, uint32_t wave);
+int ptgpu_guided_stats(ptgpu_ctx* ctx, float** device_ptr_out, size_t* count_out);
+int ptgpu_guided_end(ptgpu_ctx* ctx, double* film_rgb_out, double* film_scale_out, ptgpu_stats* stats);
+
+/* Parity hooks (no reference counterpart as an API; they expose Scene::intersect_t -> Bvh::intersect,
+ * pt/src/bvh.rs:86-142, and Scene::occluded, pt/src/scene.rs:229-235, on caller-supplied rays).
+ * rays: n * 7 floats (ox,oy,oz, dx,dy,dz, t_max). */
+int ptgpu_trace_batch(ptgpu_ctx* ctx, const float* rays, uint32_t n, ptgpu_hit* hits_out);
+/* from/to: n * 3 floats each; out[i] = 1 if Scene::occluded(from_i, to_i). */
+int ptgpu_occluded_batch(ptgpu_ctx* ctx, const float* from, const float* to, uint32_t n, uint8_t* out);
+
+/* Scene introspection for parity tests: the flattened BVH exactly as Bvh::new would lay it out.
+ * nodes_out: n_nodes * 8 uint32 words = {min.xyz, max.xyz as f32 bits, offset, n_tris | split_axis << 16};
+ * leaf_tris_out: n_tris * 2 uint32 = {mesh_index, triangle_index} in leaf order. Either may be NULL. */
+int ptgpu_scene_info(ptgpu_ctx* ctx, uint32_t* n_nodes, uint32_t* n_tris, uint32_t* n_emissive_tris, float bounds_out[6]);
+int ptgpu_scene_bvh(ptgpu_ctx* ctx, uint32_t* nodes_out, uint32_t* leaf_tris_out);
+
+/* Timing hook for bench.py: when enabled, every kernel launch is bracketed by HIP events on the library's
+ * stream and the per-stage sums are reported in ptgpu_stats (adds a sync per launch batch; off by default). */
+int ptgpu_set_profiling(ptgpu_ctx* ctx, int enabled);
+/* Per-stage totals of the last render call (valid when profiling was enabled): ms_out[i] = summed HIP-event time of
+ * the launches of stage i, launches_out[i] = their number; i = PTGPU_STAGE_*; n = entries available in the arrays. */
+enum { PTGPU_STAGE_RAYGEN = 0, PTGPU_STAGE_EXTEND = 1, PTGPU_STAGE_SHADE = 2, PTGPU_STAGE_OCCLUDE = 3, PTGPU_STAGE_RECORD = 4,
+       PTGPU_STAGE_OTHER = 5, PTGPU_N_STAGES = 6 };
+int ptgpu_kernel_times(ptgpu_ctx* ctx, double* ms_out, uint64_t* launches_out, uint32_t n);
+/* Paths kept in flight per batch (state SoA size); 0 restores the default. */
+int ptgpu_set_batch_paths(ptgpu_ctx* ctx, uint32_t n_paths);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PTGPU_H */

@@ -1,0 +1,764 @@
+// pt_device.h — per-sample device functions of the wavefront path tracer (gfx950).
+// Each block cites the reference code it replaces; the arithmetic (order, f32/f64 choice, fma sites)
+// follows it so that integer/traversal results are bit-identical and shading differs only by libm ulps.
+#pragma once
+#include "pt_math.h"
+#include "pt_types.h"
+
+namespace pt {
+
+// ------------------------------------------------------------------ sampling (pt/src/sampling.rs)
+PT_HD uint64_t mix_bits(uint64_t v) {  // sampling.rs:149-156
+    v ^= v >> 31;
+    v *= 0x7fb5d329728ea185ull;
+    v ^= v >> 27;
+    v *= 0x81dadef4bc2dd44dull;
+    v ^= v >> 33;
+    return v;
+}
+constexpr uint64_t kPcgMult = 0x5851f42d4c957f2dull;
+struct Rng {  // PCG32 XSH-RR (sampling.rs:31-70); inc is a function of the pixel, state travels with the path
+    uint64_t state, inc;
+};
+PT_HD uint32_t rng_u32(Rng& r) {
+    uint64_t old = r.state;
+    r.state = old * kPcgMult + r.inc;
+    uint32_t xs = (uint32_t)(((old >> 18) ^ old) >> 27);
+    uint32_t rot = (uint32_t)(old >> 59);
+    return (xs >> rot) | (xs << ((32u - rot) & 31u));
+}
+PT_HD float rng_f32(Rng& r) { return fminf(kOneMinusEps, (float)rng_u32(r) * 0x1p-32f); }
+PT_HD uint64_t rng_inc_for_pixel(uint32_t x, uint32_t y) { return (mix_bits(((uint64_t)x << 32) | (uint64_t)y) << 1) | 1ull; }
+// Sampler::init_pixel (sampling.rs:183-190): set_sequence(seed) then advance(0xffff * i).
+PT_HD Rng rng_init_pixel(uint32_t x, uint32_t y, uint64_t i) {
+    uint64_t seed = mix_bits(((uint64_t)x << 32) | (uint64_t)y);
+    Rng r;
+    r.state = 0;
+    r.inc = (seed << 1) | 1ull;
+    (void)rng_u32(r);
+    r.state += mix_bits(seed);
+    (void)rng_u32(r);
+    uint64_t delta = 0xffffull * i;
+    uint64_t cur_mult = kPcgMult, cur_plus = r.inc, acc_mult = 1, acc_plus = 0;
+    while (delta > 0) {
+        if (delta & 1) {
+            acc_mult *= cur_mult;
+            acc_plus = acc_plus * cur_mult + cur_plus;
+        }
+        cur_plus = (cur_mult + 1) * cur_plus;
+        cur_mult *= cur_mult;
+        delta >>= 1;
+    }
+    r.state = acc_mult * r.state + acc_plus;
+    return r;
+}
+
+PT_HD void uniform_barycentric(float u0, float u1, float b[3]) {  // sampling.rs:202-213
+    float b0 = 0.0f, b1 = 0.0f;
+    if (u0 < u1) {
+        b0 = u0 / 2.0f;
+        b1 = u1 - b0;
+    } else {
+        b1 = u1 / 2.0f;
+        b0 = u0 - b1;
+    }
+    b[0] = b0;
+    b[1] = b1;
+    b[2] = 1.0f - b0 - b1;
+}
+PT_D V3 cosine_hemisphere(float u0, float u1) {  // sampling.rs:215-219,251-255 (polar disk map)
+    float r = sqrtf(u0);
+    float theta = kTwoPi * u1;
+    float s, c;
+    sincosf(theta, &s, &c);
+    float dx = r * c, dy = r * s;
+    return mk3(dx, dy, safe_sqrtf(1.0f - dx * dx - dy * dy));
+}
+PT_HD float cosine_hemisphere_pdf(float cos_theta) { return cos_theta * kInvPi; }
+// sampling.rs:273-283. With an all-zero input 0*inf = NaN, every compare is false and the last index wins.
+PT_HD int sample_discrete4(float u, float v0, float v1, float v2, float v3) {
+    float total = ((v0 + v1) + v2) + v3;
+    float inv = 1.0f / total;
+    float sum = 0.0f;
+    sum += v0 * inv;
+    if (sum >= u) return 0;
+    sum += v1 * inv;
+    if (sum >= u) return 1;
+    sum += v2 * inv;
+    if (sum >= u) return 2;
+    return 3;
+}
+
+// ------------------------------------------------------------------ spectrum (pt/src/spectrum/mod.rs)
+struct Spec {  // SampledSpectrum = [f32; 8]
+    float v[NSW];
+};
+PT_HD Spec spec_splat(float x) {
+    Spec s;
+#pragma unroll
+    for (int i = 0; i < NSW; i++) s.v[i] = x;
+    return s;
+}
+PT_HD bool spec_is_black(const Spec& s) {
+    bool b = true;
+#pragma unroll
+    for (int i = 0; i < NSW; i++) b = b && (s.v[i] == 0.0f);
+    return b;
+}
+PT_HD bool spec_is_uniform(const Spec& s) {
+    bool b = true;
+#pragma unroll
+    for (int i = 1; i < NSW; i++) b = b && (s.v[i] == s.v[0]);
+    return b;
+}
+PT_HD float spec_average(const Spec& s) {  // mod.rs:94-96
+    float a = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NSW; i++) a += s.v[i];
+    return a / (float)NSW;
+}
+PT_HD Spec operator+(Spec a, const Spec& b) {
+#pragma unroll
+    for (int i = 0; i < NSW; i++) a.v[i] += b.v[i];
+    return a;
+}
+PT_HD Spec operator*(Spec a, const Spec& b) {
+#pragma unroll
+    for (int i = 0; i < NSW; i++) a.v[i] *= b.v[i];
+    return a;
+}
+PT_HD Spec operator*(Spec a, float s) {
+#pragma unroll
+    for (int i = 0; i < NSW; i++) a.v[i] *= s;
+    return a;
+}
+PT_HD Spec operator*(float s, Spec a) { return a * s; }
+PT_HD Spec operator/(Spec a, float s) {
+#pragma unroll
+    for (int i = 0; i < NSW; i++) a.v[i] /= s;
+    return a;
+}
+
+// Rust std f32::atanh: 0.5 * ln_1p(2|x| / (1 - |x|)) with the sign of x.
+PT_D float atanh_rs(float x) {
+    float ax = fabsf(x);
+    return copysignf(0.5f * log1pf((ax + ax) / (1.0f - ax)), x);
+}
+PT_D float sample_visible_lambda(float u) { return 538.0f - 138.888889f * atanh_rs(0.85691062f - 1.82750197f * u); }  // mod.rs:154-156
+PT_D float visible_pdf(float lambda) {  // mod.rs:157-159
+    float c = coshf(0.0072f * (lambda - 538.0f));
+    return 0.0039398042f / (c * c);
+}
+struct Lambdas {
+    float l[NSW];
+};
+PT_D Lambdas sample_visible(float u1d) {  // mod.rs:103-117
+    Lambdas r;
+#pragma unroll
+    for (int i = 0; i < NSW; i++) {
+        float u = u1d + (float)i / (float)NSW;
+        if (u >= 1.0f) u -= 1.0f;
+        r.l[i] = sample_visible_lambda(u);
+    }
+    return r;
+}
+PT_HD uint32_t lambda_index(float l) {  // (l - 360) as usize, saturating
+    float d = l - 360.0f;
+    if (!(d > 0.0f)) return 0;
+    uint32_t i = (uint32_t)d;
+    return i > (uint32_t)(CIE_N - 1) ? (uint32_t)(CIE_N - 1) : i;
+}
+// Spectrum::eval (mod.rs:303-335): sigmoid polynomial * scale (* D65 for illuminants).
+PT_D float spectrum_eval1(const SpectrumDev& s, float lambda, const float* __restrict__ d65) {
+    float x = fmaf(lambda, fmaf(lambda, s.c0, s.c1), s.c2);
+    float sig;
+    if (isinf(x)) sig = x > 0.0f ? 1.0f : 0.0f;
+    else sig = 0.5f + x / (2.0f * sqrtf(1.0f + x * x));
+    float v = sig * s.scale;
+    if (s.illuminant) v = v * d65[lambda_index(lambda)];
+    return v;
+}
+PT_D Spec spectrum_eval(const SpectrumDev& s, const Lambdas& wl, const float* __restrict__ d65) {
+    Spec r;
+#pragma unroll
+    for (int i = 0; i < NSW; i++) r.v[i] = spectrum_eval1(s, wl.l[i], d65);
+    return r;
+}
+// SampledSpectrum::to_xyz + xyz_to_rgb (mod.rs:81-90,130-136), f64. `secondary_terminated` reproduces
+// SampledWavelengths::terminate_secondary (mod.rs:118-127): pdf[0] /= 8, the others 0.
+PT_D void spec_to_rgb(const Spec& l, const Lambdas& wl, bool secondary_terminated, const double* __restrict__ cie_xyz, double rgb[3]) {
+    double X = 0.0, Y = 0.0, Z = 0.0;
+#pragma unroll
+    for (int i = 0; i < NSW; i++) {
+        float pdf = visible_pdf(wl.l[i]);
+        if (secondary_terminated) pdf = (i == 0) ? pdf / (float)NSW : 0.0f;
+        if (pdf != 0.0f) {
+            const double* c = cie_xyz + 3 * lambda_index(wl.l[i]);
+            double w = (double)(l.v[i] / pdf);
+            X += c[0] * w;
+            Y += c[1] * w;
+            Z += c[2] * w;
+        }
+    }
+    X /= (double)NSW;
+    Y /= (double)NSW;
+    Z /= (double)NSW;
+    rgb[0] = X * 3.240479 + Y * -1.537150 + Z * -0.498535;
+    rgb[1] = X * -0.969256 + Y * 1.875991 + Z * 0.041556;
+    rgb[2] = X * 0.055648 + Y * -0.204043 + Z * 1.057311;
+}
+
+// ------------------------------------------------------------------ geometry (pt/src/geom.rs)
+PT_HD V3 tri_cross(V3 p0, V3 p1, V3 p2) { return cross(p0 - p1, p2 - p1); }  // geom.rs:19-25
+PT_HD float tri_area(V3 p0, V3 p1, V3 p2) { return len(tri_cross(p0, p1, p2)) * 0.5f; }
+PT_HD V3 tri_normal(V3 p0, V3 p1, V3 p2) { return normalize(tri_cross(p0, p1, p2)); }
+PT_HD V3 tri_point(V3 p0, V3 p1, V3 p2, const float b[3]) { return p0 * b[0] + p1 * b[1] + p2 * b[2]; }
+
+// offset_ray_origin (geom.rs:48-66): leave the error box along +-n, then one ulp outward per component.
+PT_HD V3 offset_ray_origin(V3 blo, V3 bhi, V3 n, V3 w) {
+    V3 extent = max3(bhi - blo, splat(kEps));
+    float d = fabsf(dot(n, extent));
+    V3 off = d * n;
+    if (dot(w, n) < 0.0f) off = -off;
+    V3 po = (blo + bhi) / 2.0f + off;
+    po.x = off.x > 0.0f ? next_up(po.x) : next_down(po.x);
+    po.y = off.y > 0.0f ? next_up(po.y) : next_down(po.y);
+    po.z = off.z > 0.0f ? next_up(po.z) : next_down(po.z);
+    return po;
+}
+
+PT_HD V3 permute_kz(V3 v, int kz) { return kz == 0 ? mk3(v.y, v.z, v.x) : (kz == 1 ? mk3(v.z, v.x, v.y) : v); }
+PT_HD float diff_of_products(float a, float b, float c, float d) {  // geom.rs:195-200
+    float cd = c * d;
+    float dop = fmaf(a, b, -cd);
+    float e = fmaf(-c, d, cd);
+    return dop + e;
+}
+struct TriHit {
+    float t, b0, b1, b2;
+};
+// ray_triangle_intersection (geom.rs:180-287): PBRT-v4 watertight test, f64 fallback on a zero edge function.
+PT_HD bool ray_triangle(V3 ro, V3 rd, V3 p0, V3 p1, V3 p2, float max_t, TriHit& out) {
+    V3 p0t = p0 - ro, p1t = p1 - ro, p2t = p2 - ro;
+    int kz = max_axis(absv(rd));
+    V3 d = permute_kz(rd, kz);
+    p0t = permute_kz(p0t, kz);
+    p1t = permute_kz(p1t, kz);
+    p2t = permute_kz(p2t, kz);
+    float sx = -d.x / d.z, sy = -d.y / d.z, sz = 1.0f / d.z;
+    p0t.x += sx * p0t.z;
+    p0t.y += sy * p0t.z;
+    p1t.x += sx * p1t.z;
+    p1t.y += sy * p1t.z;
+    p2t.x += sx * p2t.z;
+    p2t.y += sy * p2t.z;
+    float e0 = diff_of_products(p1t.x, p2t.y, p1t.y, p2t.x);
+    float e1 = diff_of_products(p2t.x, p0t.y, p2t.y, p0t.x);
+    float e2 = diff_of_products(p0t.x, p1t.y, p0t.y, p1t.x);
+    if (e0 == 0.0f || e1 == 0.0f || e2 == 0.0f) {
+        double a = (double)p2t.x * (double)p1t.y, b = (double)p2t.y * (double)p1t.x;
+        e0 = (float)(b - a);
+        a = (double)p0t.x * (double)p2t.y;
+        b = (double)p0t.y * (double)p2t.x;
+        e1 = (float)(b - a);
+        a = (double)p1t.x * (double)p0t.y;
+        b = (double)p1t.y * (double)p0t.x;
+        e2 = (float)(b - a);
+    }
+    if ((e0 < 0.0f || e1 < 0.0f || e2 < 0.0f) && (e0 > 0.0f || e1 > 0.0f || e2 > 0.0f)) return false;
+    float det = e0 + e1 + e2;
+    if (det == 0.0f) return false;
+    p0t.z *= sz;
+    p1t.z *= sz;
+    p2t.z *= sz;
+    float t_scaled = e0 * p0t.z + e1 * p1t.z + e2 * p2t.z;
+    if (det < 0.0f && (t_scaled >= 0.0f || t_scaled < max_t * det)) return false;
+    if (det > 0.0f && (t_scaled <= 0.0f || t_scaled > max_t * det)) return false;
+    float inv_det = 1.0f / det;
+    float t = t_scaled * inv_det;
+    float max_zt = fmaxf(fmaxf(fabsf(p0t.z), fabsf(p1t.z)), fabsf(p2t.z));
+    float delta_z = gamma_n(3.0f) * max_zt;
+    float max_xt = fmaxf(fmaxf(fabsf(p0t.x), fabsf(p1t.x)), fabsf(p2t.x));
+    float max_yt = fmaxf(fmaxf(fabsf(p0t.y), fabsf(p1t.y)), fabsf(p2t.y));
+    float delta_x = gamma_n(5.0f) * (max_xt + max_zt);
+    float delta_y = gamma_n(5.0f) * (max_yt + max_zt);
+    float delta_e = 2.0f * (gamma_n(2.0f) * max_xt * max_yt + delta_y * max_xt + delta_x * max_yt);
+    float max_e = fmaxf(fmaxf(fabsf(e0), fabsf(e1)), fabsf(e2));
+    float delta_t = 3.0f * (gamma_n(3.0f) * max_e * max_zt + delta_e * max_zt + delta_z * max_e) * fabsf(inv_det);
+    if (t <= delta_t) return false;
+    out.t = t;
+    out.b0 = e0 * inv_det;
+    out.b1 = e1 * inv_det;
+    out.b2 = e2 * inv_det;
+    return true;
+}
+
+// ------------------------------------------------------------------ BVH traversal (pt/src/bvh.rs:86-146,306-327)
+// Node = two float4: {lo.xyz, bits(offset)}, {hi.xyz, bits(n_tris | split_axis << 16)}; interior nodes keep
+// their left child at index+1 and `offset` = right child. The visit order (far child pushed first, near on
+// top), the box test against the ORIGINAL ray_end_t and the "later triangle wins ties" rule are the
+// reference's, so the reported primitive is the same one bit for bit.
+struct Hit {
+    uint32_t prim;  // leaf-order triangle index, kNoHit = miss
+    TriHit th;
+};
+template <bool COUNT>
+PT_D Hit bvh_intersect(const SceneDev& sc, V3 o, V3 d, float ray_end_t, uint32_t* n_nodes_visited, uint32_t* n_tris_tested) {
+    Hit best;
+    best.prim = kNoHit;
+    best.th.t = ray_end_t;
+    best.th.b0 = best.th.b1 = best.th.b2 = 0.0f;
+    const V3 inv = splat(1.0f) / d;
+    const bool nx = inv.x < 0.0f, ny = inv.y < 0.0f, nz = inv.z < 0.0f;
+    const float slack = 1.0f + 2.0f * gamma_n(3.0f);
+    uint32_t stack[kBvhStack];
+    int sp = 0;
+    stack[sp++] = 0;
+    while (sp > 0) {
+        const uint32_t ni = stack[--sp];
+        const float4 n0 = sc.nodes[2 * ni], n1 = sc.nodes[2 * ni + 1];
+        if (COUNT) (*n_nodes_visited)++;
+        float tmin = 0.0f, tmax = ray_end_t;
+        {
+            float near_x = nx ? n1.x : n0.x, far_x = nx ? n0.x : n1.x;
+            float t0 = inv.x * (near_x - o.x);
+            float t1 = slack * inv.x * (far_x - o.x);
+            tmin = fmaxf(tmin, t0);
+            tmax = fminf(tmax, t1);
+            float near_y = ny ? n1.y : n0.y, far_y = ny ? n0.y : n1.y;
+            t0 = inv.y * (near_y - o.y);
+            t1 = slack * inv.y * (far_y - o.y);
+            tmin = fmaxf(tmin, t0);
+            tmax = fminf(tmax, t1);
+            float near_z = nz ? n1.z : n0.z, far_z = nz ? n0.z : n1.z;
+            t0 = inv.z * (near_z - o.z);
+            t1 = slack * inv.z * (far_z - o.z);
+            tmin = fmaxf(tmin, t0);
+            tmax = fminf(tmax, t1);
+        }
+        if (!((0.0f <= tmin) && (tmin <= tmax))) continue;
+        const uint32_t offset = f2u(n0.w), meta = f2u(n1.w);
+        const uint32_t ntris = meta & 0xffffu;
+        if (ntris > 0) {
+            for (uint32_t k = offset; k < offset + ntris; k++) {
+                const float4 a = sc.tri_v[3 * k], b = sc.tri_v[3 * k + 1], c = sc.tri_v[3 * k + 2];
+                if (COUNT) (*n_tris_tested)++;
+                TriHit th;
+                if (ray_triangle(o, d, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), best.th.t, th)) {
+                    best.th = th;
+                    best.prim = k;
+                }
+            }
+        } else {
+            const uint32_t axis = meta >> 16;
+            const bool neg = axis == 0 ? nx : (axis == 1 ? ny : nz);
+            if (sp + 2 <= kBvhStack) {
+                if (neg) {
+                    stack[sp++] = ni + 1;
+                    stack[sp++] = offset;
+                } else {
+                    stack[sp++] = offset;
+                    stack[sp++] = ni + 1;
+                }
+            }
+        }
+    }
+    if (!(best.th.t != ray_end_t)) best.prim = kNoHit;  // bvh.rs:137
+    return best;
+}
+// Scene::occluded (scene.rs:229-235): unnormalised segment, t_max 0.9999, full closest-hit like Bvh::hit.
+PT_D bool scene_occluded(const SceneDev& sc, V3 from, V3 to) {
+    Hit h = bvh_intersect<false>(sc, from, to - from, 0.9999f, nullptr, nullptr);
+    return h.prim != kNoHit;
+}
+
+// ------------------------------------------------------------------ shading-space helpers (pt/src/sg.rs)
+PT_HD bool same_hemisphere(V3 a, V3 b) { return a.z * b.z > 0.0f; }
+PT_HD float cos2theta(V3 v) { return v.z * v.z; }
+PT_HD float sin2theta(V3 v) { return fmaxf(1.0f - cos2theta(v), 0.0f); }
+PT_HD float tan2theta(V3 v) { return sin2theta(v) / cos2theta(v); }
+PT_HD float cos_phi(V3 v) {
+    float st = sqrtf(sin2theta(v));
+    return st == 0.0f ? 1.0f : clampf(v.x / st, -1.0f, 1.0f);
+}
+PT_HD float sin_phi(V3 v) {
+    float st = sqrtf(sin2theta(v));
+    return st == 0.0f ? 0.0f : clampf(v.y / st, -1.0f, 1.0f);
+}
+
+// ------------------------------------------------------------------ BSDFs (pt/src/bsdfs.rs)
+struct Cx {
+    float re, im;
+};
+PT_HD Cx cx_mul(Cx a, Cx b) { return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
+PT_HD Cx cx_add(Cx a, Cx b) { return {a.re + b.re, a.im + b.im}; }
+PT_HD Cx cx_sub(Cx a, Cx b) { return {a.re - b.re, a.im - b.im}; }
+PT_HD float cx_norm2(Cx a) { return a.re * a.re + a.im * a.im; }
+PT_HD Cx cx_div(Cx a, Cx b) {
+    float n = cx_norm2(b);
+    return {(a.re * b.re + a.im * b.im) / n, (a.im * b.re - a.re * b.im) / n};
+}
+PT_D Cx cx_sqrt(Cx a) {  // num-complex 0.4 Complex::sqrt (polar form with the axis special cases)
+    if (a.im == 0.0f) {
+        if (!signbit(a.re)) return {sqrtf(a.re), a.im};
+        float im = sqrtf(-a.re);
+        return {0.0f, signbit(a.im) ? -im : im};
+    } else if (a.re == 0.0f) {
+        float x = sqrtf(fabsf(a.im) / 2.0f);
+        return {x, signbit(a.im) ? -x : x};
+    }
+    float r = hypotf(a.re, a.im);
+    float th = atan2f(a.im, a.re) / 2.0f;
+    float sr = sqrtf(r), s, c;
+    sincosf(th, &s, &c);
+    return {sr * c, sr * s};
+}
+PT_HD float fresnel_dielectric(float cos_i, float eta) {  // bsdfs.rs:316-331
+    cos_i = clampf(cos_i, -1.0f, 1.0f);
+    if (cos_i < 0.0f) {
+        eta = 1.0f / eta;
+        cos_i = -cos_i;
+    }
+    float s2i = 1.0f - cos_i * cos_i;
+    float s2t = s2i / (eta * eta);
+    if (s2t >= 1.0f) return 1.0f;
+    float cos_t = safe_sqrtf(1.0f - s2t);
+    float r_parl = (eta * cos_i - cos_t) / (eta * cos_i + cos_t);
+    float r_perp = (cos_i - eta * cos_t) / (cos_i + eta * cos_t);
+    return (r_parl * r_parl + r_perp * r_perp) / 2.0f;
+}
+PT_D float fresnel_complex(float cos_i, Cx eta) {  // bsdfs.rs:333-343
+    cos_i = clampf(cos_i, 0.0f, 1.0f);
+    float s2i = 1.0f - cos_i * cos_i;
+    Cx s2t = cx_div(Cx{s2i, 0.0f}, cx_mul(eta, eta));
+    Cx cos_t = cx_sqrt(cx_sub(Cx{1.0f, 0.0f}, s2t));
+    Cx ci{cos_i, 0.0f};
+    Cx r_parl = cx_div(cx_sub(cx_mul(eta, ci), cos_t), cx_add(cx_mul(eta, ci), cos_t));
+    Cx r_perp = cx_div(cx_sub(ci, cx_mul(eta, cos_t)), cx_add(ci, cx_mul(eta, cos_t)));
+    return (cx_norm2(r_parl) + cx_norm2(r_perp)) / 2.0f;
+}
+PT_D Spec fresnel_complex_spec(float cos_i, const Spec& eta, const Spec& k) {
+    Spec r;
+#pragma unroll
+    for (int i = 0; i < NSW; i++) r.v[i] = fresnel_complex(cos_i, Cx{eta.v[i], k.v[i]});
+    return r;
+}
+PT_HD bool ggx_smooth(float a) { return a < 0.0001f; }
+PT_D V3 ggx_sample_wm(float a, V3 wo, float u0, float u1) {  // bsdfs.rs:359-369
+    V3 wi = wo.z < 0.0f ? -wo : wo;
+    V3 ws = mk3(wi.x * a, wi.y * a, wi.z);
+    float phi = (2.0f * u0 - 1.0f) * kPi;
+    float z = fmaf(1.0f - u1, 1.0f + ws.z, -ws.z);
+    float st = safe_sqrtf(1.0f - z * z);
+    float s, c;
+    sincosf(phi, &s, &c);
+    V3 wm = ws + mk3(st * c, st * s, z);
+    return normalize(mk3(wm.x * a, wm.y * a, wm.z));
+}
+PT_HD float ggx_lambda(float a, V3 w) {  // bsdfs.rs:391-397
+    float t2 = tan2theta(w);
+    if (isinf(t2)) return 0.0f;
+    return (sqrtf(1.0f + a * a * t2) - 1.0f) / 2.0f;
+}
+PT_HD float ggx_g1(float a, V3 w) { return 1.0f / (1.0f + ggx_lambda(a, w)); }
+PT_HD float ggx_g(float a, V3 wo, V3 wi) { return 1.0f / (1.0f + ggx_lambda(a, wo) + ggx_lambda(a, wi)); }
+PT_HD float ggx_d(float a, V3 wm) {  // bsdfs.rs:370-378
+    float t2 = tan2theta(wm);
+    if (isinf(t2)) return 0.0f;
+    float c2 = cos2theta(wm);
+    float c4 = c2 * c2;
+    float cpa = cos_phi(wm) / a, spa = sin_phi(wm) / a;
+    float e = t2 * (cpa * cpa + spa * spa);
+    float ope = 1.0f + e;
+    return 1.0f / (kPi * a * a * c4 * (ope * ope));
+}
+PT_HD float ggx_d_visible(float a, V3 w, V3 wm) { return ggx_g1(a, w) / fabsf(w.z) * ggx_d(a, wm) * fabsf(dot(w, wm)); }  // bsdfs.rs:379-384
+PT_HD V3 reflect_about(V3 w, V3 n) { return -w + 2.0f * dot(w, n) * n; }
+PT_HD float shading_normal_correction(V3 wo, V3 wi, V3 ng, V3 ns) {  // bsdfs.rs:130-134
+    float a = dot(wo, ns) * dot(wi, ng);
+    float b = dot(wo, ng) * dot(wi, ns);
+    return b == 0.0f ? 0.0f : fabsf(a / b);
+}
+
+struct Bsdf {  // scene::compute_bsdf result (scene.rs:236-256)
+    int kind;
+    float roughness;
+    Spec a, b;  // albedo | eta ; conductor k
+};
+struct BsdfSample {
+    Spec f;
+    V3 wi;
+    float pdf;
+    bool specular, terminate_secondary;
+};
+PT_HD bool bsdf_is_specular(const Bsdf& m) { return m.kind == MAT_DIELECTRIC || (m.kind == MAT_CONDUCTOR && ggx_smooth(m.roughness)); }
+
+PT_D Spec conductor_f(const Bsdf& m, V3 wo, V3 wi, V3 wm) {
+    float co = fabsf(wo.z), ci = fabsf(wi.z);
+    return fabsf(wi.z) * fresnel_complex_spec(fabsf(dot(wo, wm)), m.a, m.b) * ggx_d(m.roughness, wm) * ggx_g(m.roughness, wo, wi) / (4.0f * co * ci);
+}
+// BSDF::sample in shading space (bsdfs.rs:136-156,172-205,220-259). `radiance` = TransportMode::Radiance.
+PT_D bool bsdf_sample_local(const Bsdf& m, V3 wo, float u1d, float u0, float u1, bool radiance, BsdfSample& s) {
+    if (m.kind == MAT_LAMBERTIAN) {
+        V3 wi = cosine_hemisphere(u0, u1);
+        if (!same_hemisphere(wo, wi)) wi = -wi;
+        float pdf = cosine_hemisphere_pdf(fabsf(wi.z));
+        if (pdf == 0.0f) return false;
+        s.f = m.a * fabsf(wi.z) * kInvPi;
+        s.wi = wi;
+        s.pdf = pdf;
+        s.specular = false;
+        s.terminate_secondary = false;
+        return true;
+    }
+    if (m.kind == MAT_DIELECTRIC) {
+        float eta = m.a.v[0];
+        float R = fresnel_dielectric(wo.z, eta);
+        if (u1d < R) {
+            s.wi = mk3(-wo.x, -wo.y, wo.z);
+            s.f = spec_splat(R);
+            s.pdf = R;
+            s.specular = true;
+            s.terminate_secondary = false;
+            return true;
+        }
+        // refract(wo, +z, eta) (bsdfs.rs:293-314)
+        float cos_i = wo.z;
+        V3 n = mk3(0.0f, 0.0f, 1.0f);
+        if (cos_i < 0.0f) {
+            eta = 1.0f / eta;
+            cos_i = -cos_i;
+            n = -n;
+        }
+        float s2i = fmaxf(0.0f, 1.0f - cos_i * cos_i);
+        float s2t = s2i / (eta * eta);
+        if (!(s2t < 1.0f)) return false;  // unreachable in the reference (asserts); path ends here
+        float cos_t = safe_sqrtf(1.0f - s2t);
+        V3 wt = -wo / eta + (cos_i / eta - cos_t) * n;
+        float f = 1.0f - R;
+        if (radiance) f /= eta * eta;
+        s.f = spec_splat(f);
+        s.wi = wt;
+        s.pdf = 1.0f - R;
+        s.specular = true;
+        s.terminate_secondary = !spec_is_uniform(m.a);
+        return true;
+    }
+    float al = m.roughness;
+    if (ggx_smooth(al)) {
+        V3 wi = mk3(-wo.x, -wo.y, wo.z);
+        s.f = fresnel_complex_spec(wi.z, m.a, m.b);
+        s.wi = wi;
+        s.pdf = 1.0f;
+        s.specular = true;
+        s.terminate_secondary = false;
+        return true;
+    }
+    V3 wm = ggx_sample_wm(al, wo, u0, u1);
+    V3 wi = reflect_about(wo, wm);
+    if (!same_hemisphere(wo, wi)) return false;
+    s.pdf = ggx_d_visible(al, wo, wm) / (4.0f * fabsf(dot(wo, wm)));
+    s.f = conductor_f(m, wo, wi, wm);
+    s.wi = wi;
+    s.specular = false;
+    s.terminate_secondary = false;
+    return true;
+}
+PT_D Spec bsdf_eval_local(const Bsdf& m, V3 wo, V3 wi) {  // bsdfs.rs:157-162,207-209,261-279
+    if (m.kind == MAT_LAMBERTIAN) {
+        if (!same_hemisphere(wo, wi)) return spec_splat(0.0f);
+        return m.a * fabsf(wi.z) * kInvPi;
+    }
+    if (m.kind == MAT_DIELECTRIC) return spec_splat(0.0f);
+    if (ggx_smooth(m.roughness) || !same_hemisphere(wo, wi) || len2(wo + wi) == 0.0f) return spec_splat(0.0f);
+    V3 wm = normalize(wo + wi);
+    return conductor_f(m, wo, wi, wm);
+}
+PT_D float bsdf_pdf_local(const Bsdf& m, V3 wo, V3 wi) {  // bsdfs.rs:164-170,211-213,281-287
+    if (m.kind == MAT_LAMBERTIAN) return same_hemisphere(wo, wi) ? cosine_hemisphere_pdf(fabsf(wi.z)) : 0.0f;
+    if (m.kind == MAT_DIELECTRIC) return 0.0f;
+    if (ggx_smooth(m.roughness) || !same_hemisphere(wo, wi) || len2(wo + wi) == 0.0f) return 0.0f;
+    V3 wm = normalize(wo + wi);
+    return ggx_d_visible(m.roughness, wo, wm) / (4.0f * fabsf(dot(wo, wm)));
+}
+// World-space wrappers (bsdfs.rs:66-127). NB eval passes (ns, ng) where sample passes (ng, ns): kept.
+PT_D bool bsdf_sample(const Bsdf& m, const Frame& fr, V3 ng, V3 wo, float u1d, float u0, float u1, bool radiance, BsdfSample& s) {
+    if (!bsdf_sample_local(m, to_local(fr, wo), u1d, u0, u1, radiance, s)) return false;
+    V3 wi = to_world(fr, s.wi);
+    if (!radiance) s.f = s.f * shading_normal_correction(wo, wi, ng, fr.z);
+    s.wi = wi;
+    return true;
+}
+PT_D Spec bsdf_eval(const Bsdf& m, const Frame& fr, V3 ng, V3 wo, V3 wi, bool radiance) {
+    Spec f = bsdf_eval_local(m, to_local(fr, wo), to_local(fr, wi));
+    if (!radiance) f = f * shading_normal_correction(wo, wi, fr.z, ng);
+    return f;
+}
+PT_D float bsdf_pdf(const Bsdf& m, const Frame& fr, V3 wo, V3 wi) { return bsdf_pdf_local(m, to_local(fr, wo), to_local(fr, wi)); }
+
+// ------------------------------------------------------------------ scene queries (pt/src/scene.rs)
+struct Tri {
+    V3 p0, p1, p2;
+    uint32_t mesh;
+};
+PT_D Tri load_tri(const SceneDev& sc, uint32_t k) {
+    const float4 a = sc.tri_v[3 * k], b = sc.tri_v[3 * k + 1], c = sc.tri_v[3 * k + 2];
+    return Tri{mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), f2u(a.w)};
+}
+struct Surface {  // SceneInteraction (scene.rs:65-86,192-217)
+    V3 blo, bhi;   // error box around p
+    V3 ng;
+    Frame frame;   // z = ns
+    Tri tri;
+};
+PT_HD V3 surf_p(const Surface& s) { return (s.blo + s.bhi) / 2.0f; }
+PT_D Surface make_surface(const SceneDev& sc, uint32_t prim, float b0, float b1, float b2) {
+    Surface s;
+    s.tri = load_tri(sc, prim);
+    const float b[3] = {b0, b1, b2};
+    V3 p = tri_point(s.tri.p0, s.tri.p1, s.tri.p2, b);
+    V3 abs_sum = absv(s.tri.p0) * b0 + absv(s.tri.p1) * b1 + absv(s.tri.p2) * b2;
+    V3 err = gamma_n(7.0f) * abs_sum;
+    s.ng = tri_normal(s.tri.p0, s.tri.p1, s.tri.p2);
+    V3 ns = s.ng;
+    if (sc.mesh_info[s.tri.mesh].has_normals) {
+        const float4 n0 = sc.tri_n[3 * prim], n1 = sc.tri_n[3 * prim + 1], n2 = sc.tri_n[3 * prim + 2];
+        ns = normalize((mk3(n0.x, n0.y, n0.z) * b0) + (mk3(n1.x, n1.y, n1.z) * b1) + (mk3(n2.x, n2.y, n2.z) * b2));
+    }
+    s.frame = frame_from_z(ns);
+    s.blo = p - err;
+    s.bhi = p + err;
+    return s;
+}
+PT_D Bsdf make_bsdf(const SceneDev& sc, int material, const Lambdas& wl) {
+    const MaterialDev m = sc.materials[material];
+    Bsdf b;
+    b.kind = m.kind;
+    b.roughness = m.roughness;
+    b.a = spectrum_eval(m.s0, wl, sc.d65);
+    b.b = (m.kind == MAT_CONDUCTOR) ? spectrum_eval(m.s1, wl, sc.d65) : spec_splat(0.0f);
+    return b;
+}
+
+// ------------------------------------------------------------------ area lights (pt/src/lighting.rs:12-169)
+// AreaLight::emitted: one-sided along the geometric normal.
+PT_D Spec light_emitted(const SceneDev& sc, const Tri& t, V3 n, V3 from, V3 to, const Lambdas& wl) {
+    if (dot(to - from, n) <= 0.0f) return spec_splat(0.0f);
+    return spectrum_eval(sc.emissions[t.mesh], wl, sc.d65);
+}
+PT_HD float light_pdf_li(const Tri& t, V3 n, V3 from, V3 to) {  // pdf_li_solid_angle
+    float area_pdf = 1.0f / tri_area(t.p0, t.p1, t.p2);
+    V3 wl = to - from;
+    float d2 = len2(wl);
+    wl = normalize(wl);
+    float c = fabsf(dot(wl, n));
+    if (c == 0.0f) return 0.0f;
+    return area_pdf * d2 / c;
+}
+struct LightPoint {  // common part of LiSample / LeSample
+    V3 blo, bhi, n;
+    Tri tri;
+    float pmf;
+};
+// Scene::choose_light (scene.rs:257-268): uniform over emissive triangles.
+PT_D bool choose_light(const SceneDev& sc, float u, Tri& t, float& pmf) {
+    if (sc.n_emissive_tris == 0) return false;
+    uint32_t idx = (uint32_t)((float)sc.n_emissive_tris * u);
+    if (idx >= sc.n_emissive_tris) idx = sc.n_emissive_tris - 1;
+    t = load_tri(sc, sc.emissive_tris[idx]);
+    pmf = 1.0f / (float)sc.n_emissive_tris;
+    return true;
+}
+struct LiSample {
+    V3 blo, bhi, n, wl;
+    float pdf;
+    Tri tri;
+};
+PT_D bool light_sample_li(const Tri& t, V3 from, float u0, float u1, LiSample& s) {  // sample_li_solid_angle
+    float b[3];
+    uniform_barycentric(u0, u1, b);
+    V3 p = tri_point(t.p0, t.p1, t.p2, b);
+    V3 n = tri_normal(t.p0, t.p1, t.p2);
+    V3 wl = p - from;
+    if (dot(n, wl) >= 0.0f) return false;
+    float d2 = len2(wl);
+    wl = normalize(wl);
+    float area_pdf = 1.0f / tri_area(t.p0, t.p1, t.p2);
+    float c = fabsf(dot(wl, n));
+    float pdf = area_pdf * d2 / c;
+    if (pdf == 0.0f) return false;
+    V3 abs_sum = absv(t.p0) * b[0] + absv(t.p1) * b[1] + absv(t.p2) * b[2];
+    V3 err = gamma_n(6.0f) * abs_sum;
+    s.blo = p - err;
+    s.bhi = p + err;
+    s.n = n;
+    s.wl = wl;
+    s.pdf = pdf;
+    s.tri = t;
+    return true;
+}
+struct LeSample {
+    V3 blo, bhi, n, dir;
+    float pdf_dir, pdf_pos;
+};
+PT_D bool light_sample_le(const Tri& t, float u00, float u01, float u10, float u11, LeSample& s) {  // sample_le
+    float b[3];
+    uniform_barycentric(u00, u01, b);
+    V3 p = tri_point(t.p0, t.p1, t.p2, b);
+    float pdf_pos = 1.0f / tri_area(t.p0, t.p1, t.p2);
+    V3 dir = cosine_hemisphere(u10, u11);
+    float pdf_dir = cosine_hemisphere_pdf(dir.z);
+    if (pdf_dir == 0.0f) return false;
+    V3 abs_sum = absv(t.p0) * b[0] + absv(t.p1) * b[1] + absv(t.p2) * b[2];
+    V3 err = gamma_n(6.0f) * abs_sum;
+    V3 n = tri_normal(t.p0, t.p1, t.p2);
+    Frame fr = frame_from_z(n);
+    s.dir = to_world(fr, dir);
+    s.blo = p - err;
+    s.bhi = p + err;
+    s.n = n;
+    s.pdf_dir = pdf_dir;
+    s.pdf_pos = pdf_pos;
+    return true;
+}
+
+// ------------------------------------------------------------------ camera (pt/src/camera.rs:32-114)
+PT_D void camera_sample_we(const CameraDev& cam, uint32_t ix, uint32_t iy, float u0, float u1, V3& o, V3& d) {
+    float x = ((float)cam.resx * 0.5f - (float)ix - u0) * cam.pixel_size;
+    float y = ((float)cam.resy * 0.5f - (float)iy - u1) * cam.pixel_size;
+    o = mat_point(cam.c2w, mk3(0.0f, 0.0f, 0.0f));
+    d = normalize(mat_vector(cam.c2w, mk3(x, y, 1.0f)));
+}
+struct CameraWi {
+    float importance, pdf, rx, ry;
+    V3 wc;
+};
+PT_D bool camera_sample_wi(const CameraDev& cam, V3 from, CameraWi& s) {
+    V3 to_cam = cam.p - from;
+    V3 wc = normalize(to_cam);
+    V3 dir = mat_vector(cam.w2c, -wc);
+    if (dir.z <= 0.0f) return false;
+    V3 dn = dir / dir.z;
+    float W = (float)cam.resx, H = (float)cam.resy;
+    float x = W / 2.0f - dn.x / cam.pixel_size;
+    float y = H / 2.0f - dn.y / cam.pixel_size;
+    if (!((0.0f <= x && x <= W) && (0.0f <= y && y <= H))) return false;
+    float d2 = len2(to_cam);
+    float c = fabsf(dot(cam.n, wc));
+    float cz = dir.z;
+    float c4 = (cz * cz) * (cz * cz);
+    s.importance = 1.0f / (cam.pixel_size * cam.pixel_size * W * H * c4);
+    s.wc = wc;
+    s.pdf = d2 / c;
+    s.rx = x;
+    s.ry = y;
+    return true;
+}
+PT_HD uint32_t splat_pixel_index(const CameraDev& cam, float rx, float ry) {  // Film::add_splat (camera.rs:161-166)
+    uint32_t ix = rx > 0.0f ? (uint32_t)rx : 0u, iy = ry > 0.0f ? (uint32_t)ry : 0u;
+    if (ix > cam.resx - 1) ix = cam.resx - 1;
+    if (iy > cam.resy - 1) iy = cam.resy - 1;
+    return ix + iy * cam.resx;
+}
+
+}  // namespace pt

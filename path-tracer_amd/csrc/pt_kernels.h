@@ -1,0 +1,478 @@
+// pt_kernels.h — wavefront stages for the `path` and `lightpath` integrators (gfx950, wave64).
+// Every stage is a grid-stride kernel over a dense range whose length lives in device memory, so the host
+// enqueues a whole batch of bounces without reading anything back.
+#pragma once
+#include "pt_device.h"
+#include "pt_state.h"
+
+namespace pt {
+
+constexpr int kBlock = 256;
+
+// One atomic per wave: lanes with `want` get consecutive indices from *counter.
+PT_D uint32_t wave_alloc(uint32_t* counter, bool want) {
+    const unsigned long long mask = __ballot(want);
+    if (mask == 0ull) return 0;
+    const uint32_t lane = __lane_id();
+    const int leader = __ffsll((long long)mask) - 1;
+    uint32_t base = 0;
+    if ((int)lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
+    base = __shfl(base, leader);
+    return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+}
+PT_D void wave_count(uint32_t* counter, bool want) {
+    const unsigned long long mask = __ballot(want);
+    if (mask != 0ull && (int)__lane_id() == __ffsll((long long)mask) - 1) atomicAdd(counter, (uint32_t)__popcll(mask));
+}
+
+PT_D Spec load_spec(const float4* a, const float4* b, uint32_t i) {
+    const float4 x = a[i], y = b[i];
+    Spec s;
+    s.v[0] = x.x; s.v[1] = x.y; s.v[2] = x.z; s.v[3] = x.w;
+    s.v[4] = y.x; s.v[5] = y.y; s.v[6] = y.z; s.v[7] = y.w;
+    return s;
+}
+PT_D void store_spec(float4* a, float4* b, uint32_t i, const Spec& s) {
+    a[i] = make_float4(s.v[0], s.v[1], s.v[2], s.v[3]);
+    b[i] = make_float4(s.v[4], s.v[5], s.v[6], s.v[7]);
+}
+
+// SamplePixel::add / SplatPixel::add (camera.rs:138-146): f64 RGB accumulation, hardware f64 atomics.
+PT_D void film_add_rgb(double* film, uint32_t pixel, const double rgb[3]) {
+    unsafeAtomicAdd(film + 3 * (size_t)pixel + 0, rgb[0]);
+    unsafeAtomicAdd(film + 3 * (size_t)pixel + 1, rgb[1]);
+    unsafeAtomicAdd(film + 3 * (size_t)pixel + 2, rgb[2]);
+}
+PT_D void film_add(const SceneDev& sc, double* film, uint32_t pixel, const Spec& l, const Lambdas& wl, bool sec_term) {
+    double rgb[3];
+    spec_to_rgb(l, wl, sec_term, sc.cie_xyz, rgb);
+    film_add_rgb(film, pixel, rgb);
+}
+
+struct RenderParams {
+    uint32_t max_depth;
+    int mode;
+    uint32_t capacity;       // slots per state set
+    uint32_t resx;           // image width (pixel index = x + y*resx)
+    const float* lambda_u;   // wavelength-sample table (see ptgpu.hip: wavelength tables)
+    double* film;            // resx*resy*3
+};
+
+// ------------------------------------------------------------------ ray generation
+// Sampler::init_pixel + wavelength_sample + Camera::sample_we (path_tracer.rs:40-43).
+// Path g of the batch = pixel (g % n_pixels), sample slot (g / n_pixels); the sample index is
+// first_sample + slot * sample_step (multi-GPU shards interleave sample indices).
+__global__ __launch_bounds__(kBlock) void k_raygen_camera(SceneDev sc, CameraDev cam, RenderParams rp, PathCols st, RoundCounters* cnt,
+                                                          uint32_t n_paths, uint32_t n_pixels, uint64_t first_sample, uint64_t sample_step) {
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < n_paths; g += stride) {
+        const uint32_t pixel = g % n_pixels, slot = g / n_pixels;
+        const uint64_t si = first_sample + (uint64_t)slot * sample_step;
+        const uint32_t ix = pixel % cam.resx, iy = pixel / cam.resx;
+        Rng rng = rng_init_pixel(ix, iy, si);
+        const float u0 = rng_f32(rng), u1 = rng_f32(rng);
+        V3 o, d;
+        camera_sample_we(cam, ix, iy, u0, u1, o, d);
+        st.o_pdf[g] = make_float4(o.x, o.y, o.z, 0.0f);
+        st.d_flags[g] = make_float4(d.x, d.y, d.z, u2f(0u));
+        st.beta0[g] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+        st.beta1[g] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+        st.L0[g] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        st.L1[g] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        st.rng_px[g] = make_uint4((uint32_t)rng.state, (uint32_t)(rng.state >> 32), pixel, (uint32_t)si);
+        st.prev_p[g] = make_float4(0.0f, 0.0f, 0.0f, u2f(g));
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) cnt[0].n_active = n_paths;
+}
+
+// ------------------------------------------------------------------ extend (closest hit)
+// Scene::intersect -> Bvh::intersect (scene.rs:184-186, bvh.rs:86-142) for slots [0, n_active).
+__global__ __launch_bounds__(kBlock) void k_extend(SceneDev sc, PathCols st, HitCols hit, const RoundCounters* cnt) {
+    const uint32_t n = cnt->n_active;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float4 o = st.o_pdf[i], d = st.d_flags[i];
+        const Hit h = bvh_intersect<false>(sc, mk3(o.x, o.y, o.z), mk3(d.x, d.y, d.z), f_inf(), nullptr, nullptr);
+        hit.tb[i] = make_float4(h.th.t, h.th.b0, h.th.b1, h.th.b2);
+        hit.prim[i] = h.prim;
+    }
+}
+
+// Parity hook: caller-supplied rays (ox,oy,oz,dx,dy,dz,tmax) -> ptgpu_hit-shaped records + traversal counts.
+struct HitOut {
+    uint32_t mesh_index, triangle_index, leaf_index, hit;
+    float t, b0, b1, b2;
+};
+__global__ __launch_bounds__(kBlock) void k_trace_batch(SceneDev sc, const float* rays, uint32_t n, HitOut* out, unsigned long long* counts) {
+    const uint32_t stride = gridDim.x * blockDim.x;
+    unsigned long long nn = 0, nt = 0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float* r = rays + 7 * (size_t)i;
+        uint32_t a = 0, b = 0;
+        const Hit h = bvh_intersect<true>(sc, mk3(r[0], r[1], r[2]), mk3(r[3], r[4], r[5]), r[6], &a, &b);
+        nn += a;
+        nt += b;
+        HitOut o;
+        if (h.prim != kNoHit) {
+            o.mesh_index = f2u(sc.tri_v[3 * h.prim].w);
+            o.triangle_index = f2u(sc.tri_v[3 * h.prim + 1].w);
+            o.leaf_index = h.prim;
+            o.hit = 1;
+            o.t = h.th.t; o.b0 = h.th.b0; o.b1 = h.th.b1; o.b2 = h.th.b2;
+        } else {
+            o.mesh_index = o.triangle_index = o.leaf_index = o.hit = 0;
+            o.t = o.b0 = o.b1 = o.b2 = 0.0f;
+        }
+        out[i] = o;
+    }
+    if (counts) {
+        atomicAdd(counts + 0, nn);
+        atomicAdd(counts + 1, nt);
+    }
+}
+__global__ __launch_bounds__(kBlock) void k_occluded_batch(SceneDev sc, const float* from, const float* to, uint32_t n, uint8_t* out) {
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float* a = from + 3 * (size_t)i;
+        const float* b = to + 3 * (size_t)i;
+        out[i] = scene_occluded(sc, mk3(a[0], a[1], a[2]), mk3(b[0], b[1], b[2])) ? 1 : 0;
+    }
+}
+
+// ------------------------------------------------------------------ shade: `path` integrator
+// One iteration of PathIntegrator::li's loop body after the intersection (path_tracer.rs:69-180).
+__global__ __launch_bounds__(kBlock) void k_shade_path(SceneDev sc, RenderParams rp, PathCols in, HitCols hit, PathCols out, ShadowCols sh,
+                                                       const RoundCounters* cur, RoundCounters* nxt) {
+    const uint32_t n = cur->n_active;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    const uint32_t n_iter = (n + stride - 1) / stride;  // same trip count for every lane: allocs stay wave-uniform
+    for (uint32_t it = 0; it < n_iter; it++) {
+        const uint32_t i = it * stride + blockIdx.x * blockDim.x + threadIdx.x;
+        const bool valid = i < n;
+        bool alive = false, want_shadow = false, do_film = false, shaded = false;
+        V3 o = mk3(0, 0, 0), d = mk3(0, 0, 1), prev_p = mk3(0, 0, 0);
+        float prev_pdf = 0.0f;
+        uint32_t flags = 0, pid = 0;
+        Spec beta = spec_splat(0.0f), L = spec_splat(0.0f), contrib = spec_splat(0.0f);
+        uint4 rp4 = make_uint4(0, 0, 0, 0);
+        V3 sh_from = mk3(0, 0, 0), sh_to = mk3(0, 0, 0);
+        Lambdas wl;
+        if (valid) {
+            const float4 o4 = in.o_pdf[i], d4 = in.d_flags[i];
+            o = mk3(o4.x, o4.y, o4.z);
+            d = mk3(d4.x, d4.y, d4.z);
+            prev_pdf = o4.w;
+            flags = f2u(d4.w);
+            rp4 = in.rng_px[i];
+            L = load_spec(in.L0, in.L1, i);
+            wl = sample_visible(rp.lambda_u[rp4.w]);
+            const uint32_t prim = hit.prim[i];
+            if (prim == kNoHit) {
+                do_film = true;  // eval_envmap == ZERO without an envmap (scene.rs:301-306)
+            } else {
+                const float4 tb = hit.tb[i];
+                const float4 pp = in.prev_p[i];
+                prev_p = mk3(pp.x, pp.y, pp.z);
+                pid = f2u(pp.w);
+                beta = load_spec(in.beta0, in.beta1, i);
+                const Surface sf = make_surface(sc, prim, tb.y, tb.z, tb.w);
+                const int material = sc.mesh_info[sf.tri.mesh].material;
+                uint32_t depth = flags & FLAG_DEPTH_MASK;
+                if (material < 0) {
+                    // no BSDF: continue straight on, do not count a bounce (path_tracer.rs:76-80)
+                    o = offset_ray_origin(sf.blo, sf.bhi, sf.ng, d);
+                    flags |= FLAG_SPECULAR_BOUNCE;
+                    alive = true;
+                } else {
+                    shaded = true;
+                    const V3 wo = -d;
+                    const V3 p = surf_p(sf);
+                    const Bsdf bsdf = make_bsdf(sc, material, wl);
+                    const bool spec_bounce = (flags & FLAG_SPECULAR_BOUNCE) != 0;
+                    // emitted radiance of the surface that was hit (path_tracer.rs:82-108)
+                    if (sf.tri.mesh < sc.n_emissive_meshes) {
+                        const bool direct = (depth == 0) || spec_bounce;
+                        if (rp.mode == MODE_PT || direct) {
+                            L = L + light_emitted(sc, sf.tri, sf.ng, p, o, wl) * beta;
+                        } else if (rp.mode == MODE_MIS) {
+                            const float pb = prev_pdf;
+                            const float pl = light_pdf_li(sf.tri, sf.ng, prev_p, p);
+                            const float w = (pb * pb) / (pb * pb + pl * pl);
+                            L = L + w * light_emitted(sc, sf.tri, sf.ng, p, o, wl) * beta;
+                        }
+                    }
+                    Rng rng{(uint64_t)rp4.x | ((uint64_t)rp4.y << 32), rng_inc_for_pixel(rp4.z % rp.resx, rp4.z / rp.resx)};
+                    // direct lighting (path_tracer.rs:111-158); the three floats are drawn only for non-specular BSDFs
+                    if (rp.mode != MODE_PT && !bsdf_is_specular(bsdf)) {
+                        const float u1d = rng_f32(rng), ua = rng_f32(rng), ub = rng_f32(rng);
+                        Tri lt;
+                        float pmf;
+                        LiSample ls;
+                        if (choose_light(sc, u1d, lt, pmf) && light_sample_li(lt, p, ua, ub, ls)) {
+                            Spec f = bsdf_eval(bsdf, sf.frame, sf.ng, wo, ls.wl, true) / (ls.pdf * pmf);
+                            if (!spec_is_black(f)) {
+                                const V3 lp = (ls.blo + ls.bhi) / 2.0f;
+                                const Spec le = spectrum_eval(sc.emissions[lt.mesh], wl, sc.d65);
+                                if (rp.mode == MODE_NEE) contrib = f * beta * le;
+                                else {
+                                    const float pl = ls.pdf;
+                                    const float pb = bsdf_pdf(bsdf, sf.frame, wo, ls.wl);
+                                    const float w = (pl * pl) / (pl * pl + pb * pb);
+                                    contrib = w * f * beta * le;
+                                }
+                                // Scene::occluded_interaction (scene.rs:219-223)
+                                const V3 w = normalize(lp - p);
+                                sh_from = offset_ray_origin(sf.blo, sf.bhi, sf.ng, w);
+                                sh_to = lp;
+                                want_shadow = true;
+                            }
+                        }
+                    }
+                    const float u1d = rng_f32(rng), ua = rng_f32(rng), ub = rng_f32(rng);
+                    BsdfSample bs;
+                    if (bsdf_sample(bsdf, sf.frame, sf.ng, wo, u1d, ua, ub, true, bs)) {
+                        const float inv_pdf = bs.pdf;
+#pragma unroll
+                        for (int k = 0; k < NSW; k++) beta.v[k] *= bs.f.v[k] / inv_pdf;
+                        if (!spec_is_black(beta)) {
+                            flags = bs.specular ? (flags | FLAG_SPECULAR_BOUNCE) : (flags & ~FLAG_SPECULAR_BOUNCE);
+                            if (bs.terminate_secondary) flags |= FLAG_SECONDARY_TERMINATED;
+                            o = offset_ray_origin(sf.blo, sf.bhi, sf.ng, bs.wi);
+                            d = bs.wi;
+                            prev_p = p;
+                            prev_pdf = bs.pdf;
+                            depth += 1;
+                            flags = (flags & ~FLAG_DEPTH_MASK) | (depth & FLAG_DEPTH_MASK);
+                            alive = depth < rp.max_depth;
+                        }
+                    }
+                    rp4.x = (uint32_t)rng.state;
+                    rp4.y = (uint32_t)(rng.state >> 32);
+                    if (!alive && !want_shadow) do_film = true;
+                }
+            }
+        }
+        // ---- wave-uniform tail: slot allocation and stores
+        const bool want_terminal = valid && !alive && want_shadow;
+        const uint32_t a_slot = wave_alloc(&nxt->n_active, alive);
+        const uint32_t t_slot = wave_alloc(&nxt->n_terminal, want_terminal);
+        const uint32_t s_slot = wave_alloc(&nxt->n_shadow, want_shadow);
+        wave_count(&nxt->n_segments, shaded);
+        if (alive) {
+            out.o_pdf[a_slot] = make_float4(o.x, o.y, o.z, prev_pdf);
+            out.d_flags[a_slot] = make_float4(d.x, d.y, d.z, u2f(flags));
+            store_spec(out.beta0, out.beta1, a_slot, beta);
+            store_spec(out.L0, out.L1, a_slot, L);
+            out.rng_px[a_slot] = rp4;
+            out.prev_p[a_slot] = make_float4(prev_p.x, prev_p.y, prev_p.z, u2f(pid));
+        }
+        uint32_t target = a_slot;
+        if (want_terminal) {
+            const uint32_t slot = rp.capacity - 1u - t_slot;
+            store_spec(out.L0, out.L1, slot, L);
+            out.rng_px[slot] = rp4;
+            out.d_flags[slot] = make_float4(0.0f, 0.0f, 0.0f, u2f(flags));
+            target = slot | kTerminalBit;
+        }
+        if (want_shadow) {
+            sh.q0[s_slot] = make_float4(sh_from.x, sh_from.y, sh_from.z, u2f(target));
+            sh.q1[s_slot] = make_float4(sh_to.x, sh_to.y, sh_to.z, 0.0f);
+            store_spec(sh.q2, sh.q3, s_slot, contrib);
+        }
+        if (do_film && !spec_is_black(L)) film_add(sc, rp.film, rp4.z, L, wl, (flags & FLAG_SECONDARY_TERMINATED) != 0);
+    }
+}
+
+// ------------------------------------------------------------------ occlude: `path` integrator
+// Scene::occluded for the NEE shadow rays of this round; adds the MIS-weighted contribution to the path's
+// radiance and finishes paths that ended in shade with this ray still pending.
+__global__ __launch_bounds__(kBlock) void k_occlude_path(SceneDev sc, RenderParams rp, PathCols st, ShadowCols sh, const RoundCounters* cnt) {
+    const uint32_t n = cnt->n_shadow;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) {
+        const float4 a = sh.q0[j], b = sh.q1[j];
+        const bool occ = scene_occluded(sc, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z));
+        const uint32_t target = f2u(a.w);
+        const uint32_t slot = target & ~kTerminalBit;
+        if (target & kTerminalBit) {
+            Spec L = load_spec(st.L0, st.L1, slot);
+            if (!occ) L = L + load_spec(sh.q2, sh.q3, j);
+            if (!spec_is_black(L)) {
+                const uint4 rp4 = st.rng_px[slot];
+                const uint32_t flags = f2u(st.d_flags[slot].w);
+                const Lambdas wl = sample_visible(rp.lambda_u[rp4.w]);
+                film_add(sc, rp.film, rp4.z, L, wl, (flags & FLAG_SECONDARY_TERMINATED) != 0);
+            }
+        } else if (!occ) {
+            const Spec L = load_spec(st.L0, st.L1, slot) + load_spec(sh.q2, sh.q3, j);
+            store_spec(st.L0, st.L1, slot, L);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ lightpath integrator
+// LightPathIntegrator::render per-sample head (light_path_tracer.rs:27-56): emit from a light, connect the
+// emission point to the pinhole, start the random walk.
+__global__ __launch_bounds__(kBlock) void k_raygen_light(SceneDev sc, CameraDev cam, RenderParams rp, PathCols st, ShadowCols sh, RoundCounters* cnt,
+                                                         uint32_t n_paths, uint32_t n_pixels, uint64_t first_sample, uint64_t sample_step) {
+    const uint32_t stride = gridDim.x * blockDim.x;
+    const uint32_t n_iter = (n_paths + stride - 1) / stride;
+    for (uint32_t it = 0; it < n_iter; it++) {
+        const uint32_t g = it * stride + blockIdx.x * blockDim.x + threadIdx.x;
+        bool alive = false, want_splat = false;
+        V3 o = mk3(0, 0, 0), d = mk3(0, 0, 1), sh_from = mk3(0, 0, 0);
+        Spec beta = spec_splat(0.0f);
+        uint4 rp4 = make_uint4(0, 0, 0, 0);
+        double rgb[3] = {0.0, 0.0, 0.0};
+        uint32_t splat_px = 0;
+        if (g < n_paths) {
+            const uint32_t pixel = g % n_pixels, slot = g / n_pixels;
+            const uint64_t si = first_sample + (uint64_t)slot * sample_step;
+            const uint32_t ix = pixel % cam.resx, iy = pixel / cam.resx;
+            Rng rng = rng_init_pixel(ix, iy, si);
+            const Lambdas wl = sample_visible(rp.lambda_u[(uint32_t)si]);
+            const float u1d = rng_f32(rng), u00 = rng_f32(rng), u01 = rng_f32(rng), u10 = rng_f32(rng), u11 = rng_f32(rng);
+            Tri lt;
+            float pmf;
+            LeSample le;
+            if (choose_light(sc, u1d, lt, pmf) && light_sample_le(lt, u00, u01, u10, u11, le)) {
+                const Spec L = spectrum_eval(sc.emissions[lt.mesh], wl, sc.d65);
+                const V3 lp = (le.blo + le.bhi) / 2.0f;
+                CameraWi cw;
+                if (camera_sample_wi(cam, lp, cw)) {
+                    const Spec f = spec_splat(cw.importance) * L * fabsf(dot(le.n, cw.wc)) / (cw.pdf * le.pdf_pos * pmf);
+                    if (!spec_is_black(f)) {
+                        spec_to_rgb(f, wl, false, sc.cie_xyz, rgb);
+                        splat_px = splat_pixel_index(cam, cw.rx, cw.ry);
+                        const V3 w = normalize(cam.p - lp);  // Scene::occluded_le_sample (scene.rs:224-228)
+                        sh_from = offset_ray_origin(le.blo, le.bhi, le.n, w);
+                        want_splat = true;
+                    }
+                }
+                beta = L * fabsf(dot(le.n, le.dir)) / (le.pdf_pos * le.pdf_dir * pmf);
+                o = offset_ray_origin(le.blo, le.bhi, le.n, le.dir);
+                d = le.dir;
+                alive = rp.max_depth > 0;
+            }
+            rp4 = make_uint4((uint32_t)rng.state, (uint32_t)(rng.state >> 32), pixel, (uint32_t)si);
+        }
+        const uint32_t a_slot = wave_alloc(&cnt[0].n_active, alive);
+        const uint32_t s_slot = wave_alloc(&cnt[0].n_shadow, want_splat);
+        if (alive) {
+            st.o_pdf[a_slot] = make_float4(o.x, o.y, o.z, 0.0f);
+            st.d_flags[a_slot] = make_float4(d.x, d.y, d.z, u2f(0u));
+            store_spec(st.beta0, st.beta1, a_slot, beta);
+            st.rng_px[a_slot] = rp4;
+        }
+        if (want_splat) {
+            sh.q0[s_slot] = make_float4(sh_from.x, sh_from.y, sh_from.z, u2f(splat_px));
+            sh.q1[s_slot] = make_float4(cam.p.x, cam.p.y, cam.p.z, 0.0f);
+            double* r = reinterpret_cast<double*>(sh.q2);
+            r[3 * (size_t)s_slot + 0] = rgb[0];
+            r[3 * (size_t)s_slot + 1] = rgb[1];
+            r[3 * (size_t)s_slot + 2] = rgb[2];
+        }
+    }
+}
+
+// LightPathIntegrator::random_walk loop body (light_path_tracer.rs:74-118). The depth counter counts loop
+// iterations (a pass-through surface burns one, unlike `path`).
+__global__ __launch_bounds__(kBlock) void k_shade_light(SceneDev sc, CameraDev cam, RenderParams rp, PathCols in, HitCols hit, PathCols out, ShadowCols sh,
+                                                        const RoundCounters* cur, RoundCounters* nxt) {
+    const uint32_t n = cur->n_active;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    const uint32_t n_iter = (n + stride - 1) / stride;
+    for (uint32_t it = 0; it < n_iter; it++) {
+        const uint32_t i = it * stride + blockIdx.x * blockDim.x + threadIdx.x;
+        bool alive = false, want_splat = false, shaded = false;
+        V3 o = mk3(0, 0, 0), d = mk3(0, 0, 1), sh_from = mk3(0, 0, 0);
+        uint32_t flags = 0, splat_px = 0;
+        Spec beta = spec_splat(0.0f);
+        uint4 rp4 = make_uint4(0, 0, 0, 0);
+        double rgb[3] = {0.0, 0.0, 0.0};
+        if (i < n && hit.prim[i] != kNoHit) {
+            const float4 o4 = in.o_pdf[i], d4 = in.d_flags[i];
+            o = mk3(o4.x, o4.y, o4.z);
+            d = mk3(d4.x, d4.y, d4.z);
+            flags = f2u(d4.w);
+            rp4 = in.rng_px[i];
+            beta = load_spec(in.beta0, in.beta1, i);
+            const float4 tb = hit.tb[i];
+            const Lambdas wl = sample_visible(rp.lambda_u[rp4.w]);
+            const Surface sf = make_surface(sc, hit.prim[i], tb.y, tb.z, tb.w);
+            const int material = sc.mesh_info[sf.tri.mesh].material;
+            uint32_t depth = (flags & FLAG_DEPTH_MASK) + 1;  // iterations consumed including this one
+            if (material < 0) {
+                o = offset_ray_origin(sf.blo, sf.bhi, sf.ng, d);
+                alive = true;
+            } else {
+                shaded = true;
+                const V3 wo = -d;
+                const V3 p = surf_p(sf);
+                const Bsdf bsdf = make_bsdf(sc, material, wl);
+                CameraWi cw;
+                if (!bsdf_is_specular(bsdf) && camera_sample_wi(cam, p, cw)) {
+                    Spec f = bsdf_eval(bsdf, sf.frame, sf.ng, wo, cw.wc, false) * spec_splat(cw.importance) * beta / cw.pdf;
+                    if (!spec_is_black(f)) {
+                        spec_to_rgb(f, wl, (flags & FLAG_SECONDARY_TERMINATED) != 0, sc.cie_xyz, rgb);
+                        splat_px = splat_pixel_index(cam, cw.rx, cw.ry);
+                        const V3 w = normalize(cam.p - p);
+                        sh_from = offset_ray_origin(sf.blo, sf.bhi, sf.ng, w);
+                        want_splat = true;
+                    }
+                }
+                Rng rng{(uint64_t)rp4.x | ((uint64_t)rp4.y << 32), rng_inc_for_pixel(rp4.z % rp.resx, rp4.z / rp.resx)};
+                const float u1d = rng_f32(rng), ua = rng_f32(rng), ub = rng_f32(rng);
+                BsdfSample bs;
+                if (bsdf_sample(bsdf, sf.frame, sf.ng, wo, u1d, ua, ub, false, bs)) {
+                    const float pdf = bs.pdf;
+#pragma unroll
+                    for (int k = 0; k < NSW; k++) beta.v[k] *= bs.f.v[k] / pdf;
+                    if (!spec_is_black(beta)) {
+                        if (bs.terminate_secondary) flags |= FLAG_SECONDARY_TERMINATED;
+                        o = offset_ray_origin(sf.blo, sf.bhi, sf.ng, bs.wi);
+                        d = bs.wi;
+                        alive = true;
+                    }
+                }
+                rp4.x = (uint32_t)rng.state;
+                rp4.y = (uint32_t)(rng.state >> 32);
+            }
+            flags = (flags & ~FLAG_DEPTH_MASK) | (depth & FLAG_DEPTH_MASK);
+            alive = alive && depth < rp.max_depth;
+        }
+        const uint32_t a_slot = wave_alloc(&nxt->n_active, alive);
+        const uint32_t s_slot = wave_alloc(&nxt->n_shadow, want_splat);
+        wave_count(&nxt->n_segments, shaded);
+        if (alive) {
+            out.o_pdf[a_slot] = make_float4(o.x, o.y, o.z, 0.0f);
+            out.d_flags[a_slot] = make_float4(d.x, d.y, d.z, u2f(flags));
+            store_spec(out.beta0, out.beta1, a_slot, beta);
+            out.rng_px[a_slot] = rp4;
+        }
+        if (want_splat) {
+            sh.q0[s_slot] = make_float4(sh_from.x, sh_from.y, sh_from.z, u2f(splat_px));
+            sh.q1[s_slot] = make_float4(cam.p.x, cam.p.y, cam.p.z, 0.0f);
+            double* r = reinterpret_cast<double*>(sh.q2);
+            r[3 * (size_t)s_slot + 0] = rgb[0];
+            r[3 * (size_t)s_slot + 1] = rgb[1];
+            r[3 * (size_t)s_slot + 2] = rgb[2];
+        }
+    }
+}
+
+// Camera-connection visibility + Film::add_splat (camera.rs:161-166) with f64 atomics.
+__global__ __launch_bounds__(kBlock) void k_occlude_splat(SceneDev sc, RenderParams rp, ShadowCols sh, const RoundCounters* cnt) {
+    const uint32_t n = cnt->n_shadow;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    const double* r = reinterpret_cast<const double*>(sh.q2);
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) {
+        const float4 a = sh.q0[j], b = sh.q1[j];
+        if (!scene_occluded(sc, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z))) {
+            const double rgb[3] = {r[3 * (size_t)j], r[3 * (size_t)j + 1], r[3 * (size_t)j + 2]};
+            film_add_rgb(rp.film, f2u(a.w), rgb);
+        }
+    }
+}
+
+}  // namespace pt

@@ -1,0 +1,74 @@
+// pt_state.h — HBM layout of the in-flight path state (structure of arrays, 16-byte columns so every lane
+// moves whole dwordx4s and consecutive lanes touch consecutive addresses).
+//
+// One "slot" = one path. Slots are dense: the shade stage reads slot i of the `in` set and writes the
+// surviving path to a freshly allocated slot of the `out` set (wave-aggregated atomic), so every stage always
+// streams a compact [0, n_active) range — compaction is free because shade rewrites the state anyway.
+// Paths that end while a shadow ray is still pending park their radiance in slots handed out from the TOP of
+// the `out` set (capacity-1 downwards); the occlude stage finishes them.
+#pragma once
+#include "pt_types.h"
+
+namespace pt {
+
+// flags word (d_flags.w)
+constexpr uint32_t FLAG_DEPTH_MASK = 0xffffu;
+constexpr uint32_t FLAG_SPECULAR_BOUNCE = 1u << 16;
+constexpr uint32_t FLAG_SECONDARY_TERMINATED = 1u << 17;
+
+struct PathCols {
+    float4* o_pdf;    // ray origin xyz, prev_bsdf_pdf
+    float4* d_flags;  // ray direction xyz, bits(flags)
+    float4* beta0;    // throughput, wavelengths 0-3
+    float4* beta1;    //             wavelengths 4-7
+    float4* L0;       // radiance so far 0-3
+    float4* L1;       //                 4-7
+    uint4* rng_px;    // PCG state lo, hi, pixel index (x + y*W), wavelength-table index
+    float4* prev_p;   // previous interaction point xyz, bits(path id) (guided: row of the vertex store)
+};
+constexpr size_t kPathBytes = 8 * 16;  // bytes of state per slot
+
+struct HitCols {
+    float4* tb;      // t, b0, b1, b2
+    uint32_t* prim;  // leaf-order triangle index or kNoHit
+};
+constexpr size_t kHitBytes = 16 + 4;
+
+// Shadow / connection ray queue entry (64 B):
+//   q0 = {from.xyz, bits(target)}     target = slot | kTerminalBit (path), pixel (lightpath), vertex row (guided)
+//   q1 = {to.xyz, bits(aux)}
+//   q2,q3 = contribution, 8 wavelengths (path, guided) or 3 doubles RGB (lightpath)
+struct ShadowCols {
+    float4* q0;
+    float4* q1;
+    float4* q2;
+    float4* q3;
+};
+constexpr size_t kShadowBytes = 4 * 16;
+constexpr uint32_t kTerminalBit = 0x80000000u;
+
+// Per-round device counters; round r's extend/shade read c[r].n_active, shade allocates from c[r+1].
+struct RoundCounters {
+    uint32_t n_active, n_shadow, n_terminal, n_segments;
+};
+constexpr int kMaxRounds = 4096;
+
+// Guided integrator: per-path vertex store (PathVertex, path_guiding/mod.rs:281-289), vertex-major so that the
+// record pass (one lane per path) reads row v of every path coalesced: column[v * n_paths + path_id].
+struct VertexCols {
+    float4* p_pdf;    // p.xyz, wi_pdf
+    float4* wi;       // wi.xyz, -
+    float4* f0;       // f / pdf
+    float4* f1;
+    float4* e0;       // emitted
+    float4* e1;
+    float4* li0;      // li_sample_contribution (zero unless the shadow ray was unoccluded)
+    float4* li1;
+};
+constexpr size_t kVertexBytes = 8 * 16;
+struct PathTail {     // per path id, written when the walk ends (guided)
+    uint4* rng_px;    // final PCG state lo, hi, pixel, wavelength-table index
+    uint32_t* nverts_flags;  // vertex count | FLAG_SECONDARY_TERMINATED
+};
+
+}  // namespace pt

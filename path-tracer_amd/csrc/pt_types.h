@@ -1,0 +1,53 @@
+// pt_types.h — plain-data layouts shared by the host side of libptgpu and its kernels.
+#pragma once
+#include "pt_math.h"
+
+namespace pt {
+
+constexpr int NSW = 8;          // N_SAMPLED_WAVELENGTHS (pt/src/spectrum/mod.rs:6)
+constexpr int CIE_N = 471;      // 360..830 nm, 1 nm
+constexpr uint32_t kNoHit = 0xffffffffu;
+constexpr int kBvhStack = 64;   // ArrayVec<usize, 64> (pt/src/bvh.rs:94)
+
+enum { MAT_LAMBERTIAN = 0, MAT_DIELECTRIC = 1, MAT_CONDUCTOR = 2 };
+enum { MODE_PT = 0, MODE_NEE = 1, MODE_MIS = 2 };
+
+struct SpectrumDev {
+    float c0, c1, c2, scale;
+    int illuminant;
+};
+struct MaterialDev {
+    int kind;
+    float roughness;
+    SpectrumDev s0, s1;
+};
+struct MeshInfo {
+    int material;     // -1 = None (pass-through surface)
+    int has_normals;
+};
+
+// Flattened scene in HBM. Triangles are stored in BVH leaf order (Bvh::compact_triangles order):
+//   tri_v[3k+0] = {p0.xyz, bits(mesh_index)}, tri_v[3k+1] = {p1.xyz, bits(triangle_index)}, tri_v[3k+2] = {p2.xyz, 0}
+//   tri_n[3k+i] = vertex normal i (only read when mesh_info[mesh].has_normals)
+struct SceneDev {
+    const float4* nodes;
+    const float4* tri_v;
+    const float4* tri_n;
+    const MeshInfo* mesh_info;
+    const MaterialDev* materials;
+    const SpectrumDev* emissions;      // per emissive mesh (mesh_index < n_emissive_meshes <=> emitter)
+    const uint32_t* emissive_tris;     // leaf-order index of every emissive triangle, in Scene::emissive_triangles order
+    const float* d65;                  // CIE_D65_F32[471]
+    const double* cie_xyz;             // CIE_XYZ_F64[471][3]
+    uint32_t n_nodes, n_tris, n_emissive_tris, n_emissive_meshes;
+    V3 bounds_lo, bounds_hi;
+};
+
+struct CameraDev {
+    Mat4 c2w, w2c;
+    V3 p, n;  // Camera::p(), Camera::n()
+    float pixel_size;
+    uint32_t resx, resy;
+};
+
+}  // namespace pt

@@ -1,0 +1,631 @@
+// ptgpu.hip — C ABI of libptgpu.so (include/ptgpu.h): context, scene flattening, wavefront render loops.
+#include "../../include/ptgpu.h"
+
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "bvh_build.h"
+#include "cie_data.inc"
+#include "pt_guided.h"
+#include "pt_kernels.h"
+
+using namespace pt;
+
+namespace {
+
+thread_local std::string g_err;
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+#define HIP_TRY(expr)                                                                                     \
+    do {                                                                                                  \
+        hipError_t e__ = (expr);                                                                          \
+        if (e__ != hipSuccess) return fail(PTGPU_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e__)); \
+    } while (0)
+
+const float kD65[CIE_N] = {PT_CIE_D65_VALUES};
+const double kXyz[CIE_N][3] = {PT_CIE_XYZ_VALUES};
+
+template <class T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    hipError_t alloc(size_t count) {
+        release();
+        n = count;
+        if (count == 0) return hipSuccess;
+        return hipMalloc((void**)&p, count * sizeof(T));
+    }
+    hipError_t upload(const std::vector<T>& v, hipStream_t s) {
+        hipError_t e = alloc(v.size());
+        if (e != hipSuccess || v.empty()) return e;
+        e = hipMemcpyAsync(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s);
+        if (e != hipSuccess) return e;
+        return hipStreamSynchronize(s);
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    ~DevBuf() { release(); }
+};
+
+struct StateSet {
+    DevBuf<float4> cols;  // 8 columns * capacity
+    PathCols view(uint32_t cap) {
+        PathCols c;
+        float4* b = cols.p;
+        c.o_pdf = b;
+        c.d_flags = b + (size_t)cap;
+        c.beta0 = b + 2 * (size_t)cap;
+        c.beta1 = b + 3 * (size_t)cap;
+        c.L0 = b + 4 * (size_t)cap;
+        c.L1 = b + 5 * (size_t)cap;
+        c.rng_px = reinterpret_cast<uint4*>(b + 6 * (size_t)cap);
+        c.prev_p = b + 7 * (size_t)cap;
+        return c;
+    }
+};
+
+}  // namespace
+
+struct ptgpu_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int n_cus = 256;
+    // scene
+    bool have_scene = false, have_camera = false;
+    SceneDev scene{};
+    CameraDev camera{};
+    DevBuf<float4> d_nodes, d_tri_v, d_tri_n;
+    DevBuf<MeshInfo> d_mesh_info;
+    DevBuf<MaterialDev> d_materials;
+    DevBuf<SpectrumDev> d_emissions;
+    DevBuf<uint32_t> d_emissive;
+    DevBuf<float> d_d65;
+    DevBuf<double> d_xyz;
+    std::vector<uint32_t> h_nodes_words;  // 8 words per node (ptgpu_scene_bvh)
+    std::vector<uint32_t> h_leaf_tris;    // mesh, tri per leaf triangle
+    // render workspace
+    uint32_t batch_paths = 0;  // 0 = default
+    uint32_t capacity = 0;
+    StateSet set_a, set_b;
+    DevBuf<float4> d_hit_tb;
+    DevBuf<uint32_t> d_hit_prim;
+    DevBuf<float4> d_shadow;  // q0 | q1 | q2,q3 contiguous (4 * capacity)
+    DevBuf<RoundCounters> d_counters;
+    DevBuf<double> d_film;
+    DevBuf<float> d_lambda_u;
+    std::vector<RoundCounters> h_counters;
+    bool profiling = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    double stage_ms[PTGPU_N_STAGES] = {0, 0, 0, 0, 0, 0};
+    uint64_t stage_launches[PTGPU_N_STAGES] = {0, 0, 0, 0, 0, 0};
+    uint64_t launches = 0;
+    GuidedState* guided = nullptr;
+};
+
+namespace {
+
+int grid_for(const ptgpu_ctx* c, uint64_t n) {
+    const uint64_t want = (n + kBlock - 1) / kBlock;
+    const uint64_t cap = (uint64_t)c->n_cus * 8;  // <= 8 blocks of 256 per CU, grid-stride the rest
+    return (int)std::max<uint64_t>(1, std::min(want, cap));
+}
+
+SpectrumDev to_dev(const ptgpu_spectrum& s, int illuminant) { return SpectrumDev{s.c0, s.c1, s.c2, s.scale, illuminant}; }
+
+int ensure_workspace(ptgpu_ctx* c, uint32_t cap) {
+    if (c->capacity == cap && c->set_a.cols.p) return PTGPU_OK;
+    HIP_TRY(c->set_a.cols.alloc(8 * (size_t)cap));
+    HIP_TRY(c->set_b.cols.alloc(8 * (size_t)cap));
+    HIP_TRY(c->d_hit_tb.alloc(cap));
+    HIP_TRY(c->d_hit_prim.alloc(cap));
+    HIP_TRY(c->d_shadow.alloc(4 * (size_t)cap));
+    HIP_TRY(c->d_counters.alloc(kMaxRounds + 2));
+    c->h_counters.resize(kMaxRounds + 2);
+    c->capacity = cap;
+    return PTGPU_OK;
+}
+ShadowCols shadow_view(ptgpu_ctx* c) {
+    ShadowCols s;
+    const size_t cap = c->capacity;
+    s.q0 = c->d_shadow.p;
+    s.q1 = c->d_shadow.p + cap;
+    s.q2 = c->d_shadow.p + 2 * cap;  // q2 and q3 are contiguous: lightpath keeps 3 doubles per entry there
+    s.q3 = c->d_shadow.p + 3 * cap;
+    return s;
+}
+
+// Brackets one kernel launch with HIP events on the library's stream when profiling is on.
+struct StageTimer {
+    ptgpu_ctx* c;
+    int stage;
+    StageTimer(ptgpu_ctx* c_, int stage_) : c(c_), stage(stage_) {
+        if (c->profiling) (void)hipEventRecord(c->ev0, c->stream);
+    }
+    ~StageTimer() {
+        c->launches++;
+        c->stage_launches[stage]++;
+        if (c->profiling) {
+            (void)hipEventRecord(c->ev1, c->stream);
+            (void)hipEventSynchronize(c->ev1);
+            float ms = 0.0f;
+            (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
+            c->stage_ms[stage] += ms;
+        }
+    }
+};
+void reset_stage_times(ptgpu_ctx* c) {
+    for (int i = 0; i < PTGPU_N_STAGES; i++) {
+        c->stage_ms[i] = 0.0;
+        c->stage_launches[i] = 0;
+    }
+    c->launches = 0;
+}
+
+// Wavelength tables. The reference draws the hero-wavelength sample from a per-pixel additive recurrence
+// (Sampler::wavelength_sample, sampling.rs:162-193) whose state is carried sequentially: for `path` and
+// `lightpath` sample i of every pixel sees the (i+1)-th iterate of frac(state + golden); for `guided` the
+// value depends only on the pixel's position inside its 16x16 tile (path_guiding/mod.rs:89-94; see
+// build_guided_lambda_table). The tables hold the same f32 iterates the sequential code produces.
+std::vector<float> golden_iterates(size_t n) {
+    const float nn = 1.0f;
+    float inc = (nn + sqrtf(nn * nn + 4.0f)) / 2.0f;
+    inc = inc - floorf(inc);
+    std::vector<float> t(n);
+    float state = 0.0f;
+    for (size_t i = 0; i < n; i++) {
+        state += inc;
+        state -= floorf(state);
+        t[i] = state;
+    }
+    return t;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* ptgpu_last_error(void) { return g_err.c_str(); }
+
+int ptgpu_init(ptgpu_ctx** out, int device_id) {
+    if (!out) return fail(PTGPU_E_INVALID, "ptgpu_init: out is NULL");
+    *out = nullptr;
+    int n_dev = 0;
+    HIP_TRY(hipGetDeviceCount(&n_dev));
+    if (device_id < 0 || device_id >= n_dev) return fail(PTGPU_E_DEVICE, "ptgpu_init: no such HIP device");
+    HIP_TRY(hipSetDevice(device_id));
+    ptgpu_ctx* c = new ptgpu_ctx();
+    c->device = device_id;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) c->n_cus = prop.multiProcessorCount;
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreate(&c->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&c->ev1);
+    if (e == hipSuccess) e = c->d_d65.upload(std::vector<float>(kD65, kD65 + CIE_N), c->stream);
+    if (e == hipSuccess) e = c->d_xyz.upload(std::vector<double>(&kXyz[0][0], &kXyz[0][0] + 3 * CIE_N), c->stream);
+    if (e != hipSuccess) {
+        delete c;
+        return fail(PTGPU_E_DEVICE, std::string("ptgpu_init: ") + hipGetErrorString(e));
+    }
+    *out = c;
+    return PTGPU_OK;
+}
+
+void ptgpu_destroy(ptgpu_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    guided_free(c->guided);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int ptgpu_scene_create(ptgpu_ctx* c, const ptgpu_scene_desc* desc) {
+    if (!c || !desc || !desc->meshes || desc->n_meshes == 0) return fail(PTGPU_E_INVALID, "scene_create: empty description");
+    HIP_TRY(hipSetDevice(c->device));
+    // Scene::new (scene.rs:94-171): emissive meshes first, each group in input order.
+    std::vector<uint32_t> order;
+    uint32_t n_emissive_meshes = 0;
+    for (uint32_t i = 0; i < desc->n_meshes; i++)
+        if (desc->meshes[i].emissive) order.push_back(i);
+    n_emissive_meshes = (uint32_t)order.size();
+    for (uint32_t i = 0; i < desc->n_meshes; i++)
+        if (!desc->meshes[i].emissive) order.push_back(i);
+
+    std::vector<BuildTri> build;
+    std::vector<uint32_t> tri_mesh, tri_index;  // per input triangle id
+    std::vector<MeshInfo> mesh_info(order.size());
+    std::vector<SpectrumDev> emissions;
+    std::vector<uint32_t> emissive_ids;  // input triangle ids of emissive triangles, Scene::emissive_triangles order
+    for (uint32_t m = 0; m < order.size(); m++) {
+        const ptgpu_mesh& mesh = desc->meshes[order[m]];
+        if (!mesh.points || !mesh.triangles) return fail(PTGPU_E_INVALID, "scene_create: mesh without points/triangles");
+        if (mesh.material_index >= (int32_t)desc->n_materials) return fail(PTGPU_E_INVALID, "scene_create: material index out of range");
+        mesh_info[m].material = mesh.material_index < 0 ? -1 : mesh.material_index;
+        mesh_info[m].has_normals = mesh.normals ? 1 : 0;
+        if (m < n_emissive_meshes) emissions.push_back(to_dev(mesh.emission, 1));
+        for (uint32_t t = 0; t < mesh.n_triangles; t++) {
+            const uint32_t i = mesh.triangles[3 * t], j = mesh.triangles[3 * t + 1], k = mesh.triangles[3 * t + 2];
+            if (i >= mesh.n_points || j >= mesh.n_points || k >= mesh.n_points) return fail(PTGPU_E_INVALID, "scene_create: vertex index out of range");
+            const float* P = mesh.points;
+            const V3 p0 = mk3(P[3 * i], P[3 * i + 1], P[3 * i + 2]), p1 = mk3(P[3 * k], P[3 * k + 1], P[3 * k + 2]),
+                     p2 = mk3(P[3 * j], P[3 * j + 1], P[3 * j + 2]);
+            Box3 b{min3(p0, p1), max3(p0, p1)};
+            b = box_join(b, p2);
+            if (m < n_emissive_meshes) emissive_ids.push_back((uint32_t)build.size());
+            build.push_back(BuildTri{b, (uint32_t)build.size()});
+            tri_mesh.push_back(m);
+            tri_index.push_back(t);
+        }
+    }
+    if (build.empty()) return fail(PTGPU_E_INVALID, "scene_create: no triangles");
+    FlatBvh bvh;
+    if (!build_bvh(build, bvh)) return fail(PTGPU_E_LIMIT, "scene_create: a BVH leaf exceeds 65535 triangles");
+
+    const size_t n_tris = bvh.leaf_order.size(), n_nodes = bvh.nodes.size();
+    std::vector<float4> nodes(2 * n_nodes), tri_v(3 * n_tris), tri_n(3 * n_tris, make_float4(0, 0, 0, 0));
+    c->h_nodes_words.assign(8 * n_nodes, 0);
+    for (size_t i = 0; i < n_nodes; i++) {
+        const FlatNode& n = bvh.nodes[i];
+        const uint32_t meta = (uint32_t)n.n_tris | ((uint32_t)n.split_axis << 16);
+        nodes[2 * i] = make_float4(n.bounds.lo.x, n.bounds.lo.y, n.bounds.lo.z, u2f(n.offset));
+        nodes[2 * i + 1] = make_float4(n.bounds.hi.x, n.bounds.hi.y, n.bounds.hi.z, u2f(meta));
+        uint32_t* w = &c->h_nodes_words[8 * i];
+        w[0] = f2u(n.bounds.lo.x); w[1] = f2u(n.bounds.lo.y); w[2] = f2u(n.bounds.lo.z);
+        w[3] = f2u(n.bounds.hi.x); w[4] = f2u(n.bounds.hi.y); w[5] = f2u(n.bounds.hi.z);
+        w[6] = n.offset; w[7] = meta;
+    }
+    std::vector<uint32_t> leaf_of_input(n_tris);
+    c->h_leaf_tris.assign(2 * n_tris, 0);
+    bool any_normals = false;
+    for (size_t k = 0; k < n_tris; k++) {
+        const uint32_t id = bvh.leaf_order[k];
+        leaf_of_input[id] = (uint32_t)k;
+        const uint32_t m = tri_mesh[id], t = tri_index[id];
+        const ptgpu_mesh& mesh = desc->meshes[order[m]];
+        const uint32_t idx[3] = {mesh.triangles[3 * t], mesh.triangles[3 * t + 1], mesh.triangles[3 * t + 2]};
+        const uint32_t tag[3] = {m, t, 0};
+        for (int v = 0; v < 3; v++) {
+            const float* p = mesh.points + 3 * (size_t)idx[v];
+            tri_v[3 * k + v] = make_float4(p[0], p[1], p[2], u2f(tag[v]));
+            if (mesh.normals) {
+                const float* nn = mesh.normals + 3 * (size_t)idx[v];
+                tri_n[3 * k + v] = make_float4(nn[0], nn[1], nn[2], 0.0f);
+                any_normals = true;
+            }
+        }
+        c->h_leaf_tris[2 * k] = m;
+        c->h_leaf_tris[2 * k + 1] = t;
+    }
+    if (!any_normals) tri_n.assign(1, make_float4(0, 0, 0, 0));
+    std::vector<uint32_t> emissive_leaf(emissive_ids.size());
+    for (size_t i = 0; i < emissive_ids.size(); i++) emissive_leaf[i] = leaf_of_input[emissive_ids[i]];
+    std::vector<MaterialDev> mats(desc->n_materials);
+    for (uint32_t i = 0; i < desc->n_materials; i++) {
+        const ptgpu_material& m = desc->materials[i];
+        if (m.kind < 0 || m.kind > 2) return fail(PTGPU_E_INVALID, "scene_create: unknown material kind");
+        mats[i] = MaterialDev{m.kind, m.roughness, to_dev(m.s0, 0), to_dev(m.s1, 0)};
+    }
+    if (mats.empty()) mats.push_back(MaterialDev{0, 0.0f, SpectrumDev{0, 0, 0, 0, 0}, SpectrumDev{0, 0, 0, 0, 0}});
+    if (emissions.empty()) emissions.push_back(SpectrumDev{0, 0, 0, 0, 1});
+    if (emissive_leaf.empty()) emissive_leaf.push_back(0);
+
+    HIP_TRY(c->d_nodes.upload(nodes, c->stream));
+    HIP_TRY(c->d_tri_v.upload(tri_v, c->stream));
+    HIP_TRY(c->d_tri_n.upload(tri_n, c->stream));
+    HIP_TRY(c->d_mesh_info.upload(mesh_info, c->stream));
+    HIP_TRY(c->d_materials.upload(mats, c->stream));
+    HIP_TRY(c->d_emissions.upload(emissions, c->stream));
+    HIP_TRY(c->d_emissive.upload(emissive_leaf, c->stream));
+    SceneDev& s = c->scene;
+    s.nodes = c->d_nodes.p;
+    s.tri_v = c->d_tri_v.p;
+    s.tri_n = c->d_tri_n.p;
+    s.mesh_info = c->d_mesh_info.p;
+    s.materials = c->d_materials.p;
+    s.emissions = c->d_emissions.p;
+    s.emissive_tris = c->d_emissive.p;
+    s.d65 = c->d_d65.p;
+    s.cie_xyz = c->d_xyz.p;
+    s.n_nodes = (uint32_t)n_nodes;
+    s.n_tris = (uint32_t)n_tris;
+    s.n_emissive_tris = (uint32_t)emissive_ids.size();
+    s.n_emissive_meshes = n_emissive_meshes;
+    s.bounds_lo = bvh.nodes[0].bounds.lo;
+    s.bounds_hi = bvh.nodes[0].bounds.hi;
+    c->have_scene = true;
+    return PTGPU_OK;
+}
+
+int ptgpu_camera_set(ptgpu_ctx* c, const ptgpu_camera_desc* cam) {
+    if (!c || !cam || cam->resx == 0 || cam->resy == 0) return fail(PTGPU_E_INVALID, "camera_set: bad arguments");
+    if ((uint64_t)cam->resx * cam->resy > (1ull << 31)) return fail(PTGPU_E_LIMIT, "camera_set: image too large");
+    CameraDev& d = c->camera;
+    for (int r = 0; r < 4; r++)
+        for (int col = 0; col < 4; col++) d.w2c.c[col][r] = cam->world_to_camera[4 * r + col];
+    // Matrix4::inverse via adjugate / determinant (math/src/matrix.rs:109-178), same expression order.
+    {
+        const float(*m)[4] = d.w2c.c;
+        const float m00 = m[0][0], m01 = m[0][1], m02 = m[0][2], m03 = m[0][3], m10 = m[1][0], m11 = m[1][1], m12 = m[1][2], m13 = m[1][3];
+        const float m20 = m[2][0], m21 = m[2][1], m22 = m[2][2], m23 = m[2][3], m30 = m[3][0], m31 = m[3][1], m32 = m[3][2], m33 = m[3][3];
+        const float c00 = (m22 * m33) - (m32 * m23), c02 = (m12 * m33) - (m32 * m13), c03 = (m12 * m23) - (m22 * m13);
+        const float c04 = (m21 * m33) - (m31 * m23), c06 = (m11 * m33) - (m31 * m13), c07 = (m11 * m23) - (m21 * m13);
+        const float c08 = (m21 * m32) - (m31 * m22), c10 = (m11 * m32) - (m31 * m12), c11 = (m11 * m22) - (m21 * m12);
+        const float c12 = (m20 * m33) - (m30 * m23), c14 = (m10 * m33) - (m30 * m13), c15 = (m10 * m23) - (m20 * m13);
+        const float c16 = (m20 * m32) - (m30 * m22), c18 = (m10 * m32) - (m30 * m12), c19 = (m10 * m22) - (m20 * m12);
+        const float c20 = (m20 * m31) - (m30 * m21), c22 = (m10 * m31) - (m30 * m11), c23 = (m10 * m21) - (m20 * m11);
+        const float f0[4] = {c00, c00, c02, c03}, f1[4] = {c04, c04, c06, c07}, f2[4] = {c08, c08, c10, c11};
+        const float f3[4] = {c12, c12, c14, c15}, f4[4] = {c16, c16, c18, c19}, f5[4] = {c20, c20, c22, c23};
+        const float v0[4] = {m10, m00, m00, m00}, v1[4] = {m11, m01, m01, m01}, v2[4] = {m12, m02, m02, m02}, v3[4] = {m13, m03, m03, m03};
+        const float sa[4] = {1.0f, -1.0f, 1.0f, -1.0f}, sb[4] = {-1.0f, 1.0f, -1.0f, 1.0f};
+        float ad[4][4];
+        for (int i = 0; i < 4; i++) {
+            ad[0][i] = ((v1[i] * f0[i]) - (v2[i] * f1[i]) + (v3[i] * f2[i])) * sa[i];
+            ad[1][i] = ((v0[i] * f0[i]) - (v2[i] * f3[i]) + (v3[i] * f4[i])) * sb[i];
+            ad[2][i] = ((v0[i] * f1[i]) - (v1[i] * f3[i]) + (v3[i] * f5[i])) * sa[i];
+            ad[3][i] = ((v0[i] * f2[i]) - (v1[i] * f4[i]) + (v2[i] * f5[i])) * sb[i];
+        }
+        const float d0 = m[0][0] * ad[0][0], d1 = m[0][1] * ad[1][0], d2 = m[0][2] * ad[2][0], d3 = m[0][3] * ad[3][0];
+        const float recip = 1.0f / (d0 + d1 + d2 + d3);
+        for (int col = 0; col < 4; col++)
+            for (int r = 0; r < 4; r++) d.c2w.c[col][r] = ad[col][r] * recip;
+    }
+    const float half = (cam->fov_deg / 2.0f) * (kPi / 180.0f);  // f32::to_radians
+    d.pixel_size = 2.0f * tanf(half) / (float)cam->resy;
+    d.resx = cam->resx;
+    d.resy = cam->resy;
+    d.p = mat_point(d.c2w, mk3(0.0f, 0.0f, 0.0f));
+    d.n = normalize(mat_vector(d.c2w, mk3(0.0f, 0.0f, 1.0f)));
+    c->have_camera = true;
+    return PTGPU_OK;
+}
+
+int ptgpu_scene_info(ptgpu_ctx* c, uint32_t* n_nodes, uint32_t* n_tris, uint32_t* n_emissive_tris, float bounds_out[6]) {
+    if (!c || !c->have_scene) return fail(PTGPU_E_STATE, "scene_info: no scene");
+    if (n_nodes) *n_nodes = c->scene.n_nodes;
+    if (n_tris) *n_tris = c->scene.n_tris;
+    if (n_emissive_tris) *n_emissive_tris = c->scene.n_emissive_tris;
+    if (bounds_out) {
+        bounds_out[0] = c->scene.bounds_lo.x; bounds_out[1] = c->scene.bounds_lo.y; bounds_out[2] = c->scene.bounds_lo.z;
+        bounds_out[3] = c->scene.bounds_hi.x; bounds_out[4] = c->scene.bounds_hi.y; bounds_out[5] = c->scene.bounds_hi.z;
+    }
+    return PTGPU_OK;
+}
+int ptgpu_scene_bvh(ptgpu_ctx* c, uint32_t* nodes_out, uint32_t* leaf_tris_out) {
+    if (!c || !c->have_scene) return fail(PTGPU_E_STATE, "scene_bvh: no scene");
+    if (nodes_out) memcpy(nodes_out, c->h_nodes_words.data(), c->h_nodes_words.size() * 4);
+    if (leaf_tris_out) memcpy(leaf_tris_out, c->h_leaf_tris.data(), c->h_leaf_tris.size() * 4);
+    return PTGPU_OK;
+}
+
+int ptgpu_trace_batch(ptgpu_ctx* c, const float* rays, uint32_t n, ptgpu_hit* hits_out) {
+    if (!c || !c->have_scene) return fail(PTGPU_E_STATE, "trace_batch: no scene");
+    if (n == 0) return PTGPU_OK;
+    if (!rays || !hits_out) return fail(PTGPU_E_INVALID, "trace_batch: NULL buffer");
+    HIP_TRY(hipSetDevice(c->device));
+    static_assert(sizeof(HitOut) == sizeof(ptgpu_hit), "hit layout");
+    DevBuf<float> d_rays;
+    DevBuf<HitOut> d_hits;
+    HIP_TRY(d_rays.alloc(7 * (size_t)n));
+    HIP_TRY(d_hits.alloc(n));
+    HIP_TRY(hipMemcpyAsync(d_rays.p, rays, 7 * (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_trace_batch, dim3(grid_for(c, n)), dim3(kBlock), 0, c->stream, c->scene, d_rays.p, n, d_hits.p, (unsigned long long*)nullptr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(hits_out, d_hits.p, (size_t)n * sizeof(HitOut), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return PTGPU_OK;
+}
+
+int ptgpu_occluded_batch(ptgpu_ctx* c, const float* from, const float* to, uint32_t n, uint8_t* out) {
+    if (!c || !c->have_scene) return fail(PTGPU_E_STATE, "occluded_batch: no scene");
+    if (n == 0) return PTGPU_OK;
+    if (!from || !to || !out) return fail(PTGPU_E_INVALID, "occluded_batch: NULL buffer");
+    HIP_TRY(hipSetDevice(c->device));
+    DevBuf<float> d_from, d_to;
+    DevBuf<uint8_t> d_out;
+    HIP_TRY(d_from.alloc(3 * (size_t)n));
+    HIP_TRY(d_to.alloc(3 * (size_t)n));
+    HIP_TRY(d_out.alloc(n));
+    HIP_TRY(hipMemcpyAsync(d_from.p, from, 3 * (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(d_to.p, to, 3 * (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_occluded_batch, dim3(grid_for(c, n)), dim3(kBlock), 0, c->stream, c->scene, d_from.p, d_to.p, n, d_out.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out, d_out.p, n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return PTGPU_OK;
+}
+
+int ptgpu_set_profiling(ptgpu_ctx* c, int enabled) {
+    if (!c) return fail(PTGPU_E_INVALID, "set_profiling: NULL ctx");
+    c->profiling = enabled != 0;
+    return PTGPU_OK;
+}
+int ptgpu_kernel_times(ptgpu_ctx* c, double* ms_out, uint64_t* launches_out, uint32_t n) {
+    if (!c) return fail(PTGPU_E_INVALID, "kernel_times: NULL ctx");
+    for (uint32_t i = 0; i < n && i < PTGPU_N_STAGES; i++) {
+        if (ms_out) ms_out[i] = c->stage_ms[i];
+        if (launches_out) launches_out[i] = c->stage_launches[i];
+    }
+    return PTGPU_OK;
+}
+int ptgpu_set_batch_paths(ptgpu_ctx* c, uint32_t n_paths) {
+    if (!c) return fail(PTGPU_E_INVALID, "set_batch_paths: NULL ctx");
+    c->batch_paths = n_paths;
+    return PTGPU_OK;
+}
+
+}  // extern "C"
+
+namespace {
+
+uint32_t pick_capacity(const ptgpu_ctx* c, uint64_t total_paths) {
+    uint64_t cap = c->batch_paths ? c->batch_paths : (1ull << 22);
+    const uint64_t npix = (uint64_t)c->camera.resx * c->camera.resy;
+    if (cap < npix) cap = npix;                     // a batch always covers whole sample passes
+    cap = (cap / npix) * npix;
+    if (cap > total_paths) cap = ((total_paths + npix - 1) / npix) * npix;
+    return (uint32_t)std::min<uint64_t>(cap, 0x7fffffffull);
+}
+
+// One batch of camera or light paths through all bounces. Returns the number of rounds run.
+int run_batch_path_like(ptgpu_ctx* c, bool light, const RenderParams& rp, uint32_t n_paths, uint64_t first_sample, uint64_t sample_step,
+                        ptgpu_stats* stats) {
+    const uint32_t npix = c->camera.resx * c->camera.resy;
+    HIP_TRY(hipMemsetAsync(c->d_counters.p, 0, c->d_counters.n * sizeof(RoundCounters), c->stream));
+    PathCols A = c->set_a.view(c->capacity), B = c->set_b.view(c->capacity);
+    HitCols H{c->d_hit_tb.p, c->d_hit_prim.p};
+    ShadowCols S = shadow_view(c);
+    RoundCounters* cnt = c->d_counters.p;
+    const int grid = grid_for(c, n_paths);
+    if (light) {
+        {
+            StageTimer t(c, PTGPU_STAGE_RAYGEN);
+            hipLaunchKernelGGL(k_raygen_light, dim3(grid), dim3(kBlock), 0, c->stream, c->scene, c->camera, rp, A, S, cnt, n_paths, npix, first_sample, sample_step);
+        }
+        StageTimer t(c, PTGPU_STAGE_OCCLUDE);
+        hipLaunchKernelGGL(k_occlude_splat, dim3(grid), dim3(kBlock), 0, c->stream, c->scene, rp, S, cnt);
+    } else {
+        StageTimer t(c, PTGPU_STAGE_RAYGEN);
+        hipLaunchKernelGGL(k_raygen_camera, dim3(grid), dim3(kBlock), 0, c->stream, c->scene, c->camera, rp, A, cnt, n_paths, npix, first_sample, sample_step);
+    }
+    HIP_TRY(hipGetLastError());
+    int round = 0;
+    // Rounds needed: max_depth for paths that never meet a pass-through surface; more only if they do.
+    const int sure_rounds = (int)std::min<uint32_t>(rp.max_depth, kMaxRounds);
+    for (;;) {
+        if (round >= kMaxRounds) return fail(PTGPU_E_LIMIT, "render: more than 4096 wavefront rounds in one batch");
+        {
+            StageTimer t(c, PTGPU_STAGE_EXTEND);
+            hipLaunchKernelGGL(k_extend, dim3(grid), dim3(kBlock), 0, c->stream, c->scene, A, H, cnt + round);
+        }
+        {
+            StageTimer t(c, PTGPU_STAGE_SHADE);
+            if (light)
+                hipLaunchKernelGGL(k_shade_light, dim3(grid), dim3(kBlock), 0, c->stream, c->scene, c->camera, rp, A, H, B, S, cnt + round, cnt + round + 1);
+            else
+                hipLaunchKernelGGL(k_shade_path, dim3(grid), dim3(kBlock), 0, c->stream, c->scene, rp, A, H, B, S, cnt + round, cnt + round + 1);
+        }
+        {
+            StageTimer t(c, PTGPU_STAGE_OCCLUDE);
+            if (light) hipLaunchKernelGGL(k_occlude_splat, dim3(grid), dim3(kBlock), 0, c->stream, c->scene, rp, S, cnt + round + 1);
+            else hipLaunchKernelGGL(k_occlude_path, dim3(grid), dim3(kBlock), 0, c->stream, c->scene, rp, B, S, cnt + round + 1);
+        }
+        HIP_TRY(hipGetLastError());
+        std::swap(A, B);
+        round++;
+        if (round >= sure_rounds || (round & 3) == 0) {
+            RoundCounters rc;
+            HIP_TRY(hipMemcpyAsync(&rc, cnt + round, sizeof(rc), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            if (rc.n_active == 0) break;
+        }
+    }
+    if (stats) {
+        HIP_TRY(hipMemcpyAsync(c->h_counters.data(), cnt, (size_t)(round + 1) * sizeof(RoundCounters), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        for (int r = 0; r <= round; r++) {
+            stats->extend_rays += c->h_counters[r].n_active;
+            stats->shadow_rays += c->h_counters[r].n_shadow;
+            stats->segments += c->h_counters[r].n_segments;
+        }
+        stats->samples += n_paths;
+    }
+    return PTGPU_OK;
+}
+
+int render_path_like(ptgpu_ctx* c, const ptgpu_integrator_desc* integ, uint32_t spp, uint32_t shard_index, uint32_t shard_count, ptgpu_stats* stats) {
+    const bool light = integ->kind == PTGPU_INTEGRATOR_LIGHTPATH;
+    const uint64_t npix = (uint64_t)c->camera.resx * c->camera.resy;
+    // this shard's samples: i = shard_index, shard_index + shard_count, ...
+    const uint64_t my_samples = spp > shard_index ? ((uint64_t)spp - shard_index + shard_count - 1) / shard_count : 0;
+    HIP_TRY(hipMemsetAsync(c->d_film.p, 0, c->d_film.n * sizeof(double), c->stream));
+    if (my_samples == 0 || integ->max_depth == 0) return PTGPU_OK;
+    int rc = ensure_workspace(c, pick_capacity(c, my_samples * npix));
+    if (rc != PTGPU_OK) return rc;
+    HIP_TRY(c->d_lambda_u.upload(golden_iterates(spp), c->stream));
+    RenderParams rp;
+    rp.max_depth = integ->max_depth > 0xffffu ? 0xffffu : integ->max_depth;
+    rp.mode = integ->mode;
+    rp.capacity = c->capacity;
+    rp.resx = c->camera.resx;
+    rp.lambda_u = c->d_lambda_u.p;
+    rp.film = c->d_film.p;
+    const uint64_t passes_per_batch = c->capacity / npix;
+    for (uint64_t done = 0; done < my_samples; done += passes_per_batch) {
+        const uint64_t passes = std::min(passes_per_batch, my_samples - done);
+        const uint64_t first = shard_index + done * shard_count;
+        rc = run_batch_path_like(c, light, rp, (uint32_t)(passes * npix), first, shard_count, stats);
+        if (rc != PTGPU_OK) return rc;
+    }
+    return PTGPU_OK;
+}
+
+int check_render_args(ptgpu_ctx* c, const ptgpu_integrator_desc* integ, uint32_t shard_index, uint32_t shard_count) {
+    if (!c || !integ) return fail(PTGPU_E_INVALID, "render: NULL argument");
+    if (!c->have_scene || !c->have_camera) return fail(PTGPU_E_STATE, "render: scene_create and camera_set must come first");
+    if (shard_count == 0 || shard_index >= shard_count) return fail(PTGPU_E_INVALID, "render: bad shard");
+    if (integ->kind < 0 || integ->kind > 2) return fail(PTGPU_E_INVALID, "render: unknown integrator");
+    if (integ->kind != PTGPU_INTEGRATOR_LIGHTPATH && (integ->mode < 0 || integ->mode > 2)) return fail(PTGPU_E_INVALID, "render: unknown mode");
+    return PTGPU_OK;
+}
+
+int download_film(ptgpu_ctx* c, double* film_out) {
+    if (film_out) {
+        HIP_TRY(hipMemcpyAsync(film_out, c->d_film.p, c->d_film.n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return PTGPU_OK;
+}
+
+}  // namespace
+
+#include "ptgpu_guided_api.inc"
+
+extern "C" {
+
+int ptgpu_render_shard(ptgpu_ctx* c, const ptgpu_integrator_desc* integ, uint32_t spp, uint32_t shard_index, uint32_t shard_count,
+                       double* film_rgb_out, double* film_scale_out, ptgpu_stats* stats) {
+    int rc = check_render_args(c, integ, shard_index, shard_count);
+    if (rc != PTGPU_OK) return rc;
+    if (spp == 0) return fail(PTGPU_E_INVALID, "render: spp must be > 0");
+    HIP_TRY(hipSetDevice(c->device));
+    if (stats) memset(stats, 0, sizeof(*stats));
+    reset_stage_times(c);
+    const auto t0 = std::chrono::steady_clock::now();
+    const size_t film_n = (size_t)c->camera.resx * c->camera.resy * 3;
+    if (c->d_film.n != film_n) HIP_TRY(c->d_film.alloc(film_n));
+    if (integ->kind == PTGPU_INTEGRATOR_GUIDED) {
+        uint32_t n_waves = 0;
+        rc = ptgpu_guided_begin(c, integ, spp, shard_index, shard_count, &n_waves);
+        for (uint32_t w = 0; rc == PTGPU_OK && w < n_waves; w++) rc = ptgpu_guided_wave(c, w);
+        if (rc != PTGPU_OK) return rc;
+        return ptgpu_guided_end(c, film_rgb_out, film_scale_out, stats);
+    }
+    rc = render_path_like(c, integ, spp, shard_index, shard_count, stats);
+    if (rc != PTGPU_OK) return rc;
+    rc = download_film(c, film_rgb_out);
+    if (rc != PTGPU_OK) return rc;
+    if (film_scale_out) *film_scale_out = 1.0 / (double)spp;  // Integrator::film_scale (integrator/mod.rs:47-50)
+    if (stats) {
+        stats->render_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        stats->extend_ms = c->stage_ms[PTGPU_STAGE_EXTEND] + c->stage_ms[PTGPU_STAGE_OCCLUDE];
+        stats->shade_ms = c->stage_ms[PTGPU_STAGE_SHADE];
+        stats->kernel_launches = c->launches;
+    }
+    return PTGPU_OK;
+}
+
+int ptgpu_render(ptgpu_ctx* c, const ptgpu_integrator_desc* integ, uint32_t spp, double* film_rgb_out, double* film_scale_out, ptgpu_stats* stats) {
+    return ptgpu_render_shard(c, integ, spp, 0, 1, film_rgb_out, film_scale_out, stats);
+}
+
+}  // extern "C"

@@ -1,0 +1,1129 @@
+// pthost.cpp — host side above the hot path (include/pthost.h): scene_v3.xml loader, spectrum upsampling,
+// film writer. C++ stand-in for the reference's Rust host; cites pt/src/parser/mod.rs throughout.
+#include "../../include/pthost.h"
+
+#include <dlfcn.h>
+#include <sys/stat.h>
+
+#include <algorithm>
+#include <array>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <memory>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "../csrc/cie_data.inc"
+
+namespace {
+
+thread_local std::string g_err;
+struct Error {
+    std::string msg;
+};
+[[noreturn]] void die(const std::string& m) { throw Error{m}; }
+
+// ------------------------------------------------------------------ minimal XML DOM (elements + attributes)
+struct XmlNode {
+    std::string tag;
+    std::vector<std::pair<std::string, std::string>> attrs;
+    std::vector<std::unique_ptr<XmlNode>> children;
+    const std::string* attr(const std::string& k) const {
+        for (auto& a : attrs)
+            if (a.first == k) return &a.second;
+        return nullptr;
+    }
+};
+struct XmlParser {
+    const std::string& s;
+    size_t i = 0;
+    explicit XmlParser(const std::string& src) : s(src) {}
+    void skip_ws() {
+        while (i < s.size() && isspace((unsigned char)s[i])) i++;
+    }
+    bool starts(const char* lit) const { return s.compare(i, strlen(lit), lit) == 0; }
+    void skip_misc() {  // whitespace, text, comments, declarations
+        for (;;) {
+            while (i < s.size() && s[i] != '<') i++;
+            if (i >= s.size()) return;
+            if (starts("<!--")) {
+                size_t e = s.find("-->", i + 4);
+                if (e == std::string::npos) die("xml: unterminated comment");
+                i = e + 3;
+            } else if (starts("<?")) {
+                size_t e = s.find("?>", i + 2);
+                if (e == std::string::npos) die("xml: unterminated declaration");
+                i = e + 2;
+            } else if (starts("<!")) {
+                size_t e = s.find('>', i);
+                if (e == std::string::npos) die("xml: unterminated <!");
+                i = e + 1;
+            } else
+                return;
+        }
+    }
+    std::string name() {
+        size_t b = i;
+        while (i < s.size() && (isalnum((unsigned char)s[i]) || s[i] == '_' || s[i] == '-' || s[i] == ':' || s[i] == '.')) i++;
+        if (b == i) die("xml: expected a name at offset " + std::to_string(i));
+        return s.substr(b, i - b);
+    }
+    std::unique_ptr<XmlNode> element() {
+        if (i >= s.size() || s[i] != '<') die("xml: expected '<'");
+        i++;
+        auto n = std::make_unique<XmlNode>();
+        n->tag = name();
+        for (;;) {
+            skip_ws();
+            if (i >= s.size()) die("xml: unexpected end in <" + n->tag + ">");
+            if (s[i] == '/') {
+                if (i + 1 >= s.size() || s[i + 1] != '>') die("xml: bad empty-element tag");
+                i += 2;
+                return n;
+            }
+            if (s[i] == '>') {
+                i++;
+                break;
+            }
+            std::string k = name();
+            skip_ws();
+            if (i >= s.size() || s[i] != '=') die("xml: expected '=' after attribute " + k);
+            i++;
+            skip_ws();
+            if (i >= s.size() || (s[i] != '"' && s[i] != '\'')) die("xml: expected quoted value for " + k);
+            const char q = s[i++];
+            size_t e = s.find(q, i);
+            if (e == std::string::npos) die("xml: unterminated attribute value");
+            n->attrs.emplace_back(k, s.substr(i, e - i));
+            i = e + 1;
+        }
+        for (;;) {
+            skip_misc();
+            if (i >= s.size()) die("xml: missing </" + n->tag + ">");
+            if (starts("</")) {
+                i += 2;
+                std::string c = name();
+                if (c != n->tag) die("xml: mismatched </" + c + "> for <" + n->tag + ">");
+                skip_ws();
+                if (i >= s.size() || s[i] != '>') die("xml: bad end tag");
+                i++;
+                return n;
+            }
+            n->children.push_back(element());
+        }
+    }
+    std::unique_ptr<XmlNode> document() {
+        skip_misc();
+        return element();
+    }
+};
+
+// ------------------------------------------------------------------ 4x4 matrices (math/src/matrix.rs), column-major
+struct M4 {
+    float c[4][4];  // c[col][row]
+};
+M4 m_identity() {
+    M4 m{};
+    for (int i = 0; i < 4; i++) m.c[i][i] = 1.0f;
+    return m;
+}
+M4 m_from_rows(const float r[16]) {
+    M4 m;
+    for (int row = 0; row < 4; row++)
+        for (int col = 0; col < 4; col++) m.c[col][row] = r[4 * row + col];
+    return m;
+}
+M4 m_mul(const M4& a, const M4& b) {  // matrix.rs:51-90: column j = a.col0*b[j].x + a.col1*b[j].y + ...
+    M4 r;
+    for (int j = 0; j < 4; j++)
+        for (int k = 0; k < 4; k++) r.c[j][k] = (a.c[0][k] * b.c[j][0]) + (a.c[1][k] * b.c[j][1]) + (a.c[2][k] * b.c[j][2]) + (a.c[3][k] * b.c[j][3]);
+    return r;
+}
+M4 m_inverse(const M4& m) {  // matrix.rs:109-178
+    const float m00 = m.c[0][0], m01 = m.c[0][1], m02 = m.c[0][2], m03 = m.c[0][3], m10 = m.c[1][0], m11 = m.c[1][1], m12 = m.c[1][2], m13 = m.c[1][3];
+    const float m20 = m.c[2][0], m21 = m.c[2][1], m22 = m.c[2][2], m23 = m.c[2][3], m30 = m.c[3][0], m31 = m.c[3][1], m32 = m.c[3][2], m33 = m.c[3][3];
+    const float c00 = (m22 * m33) - (m32 * m23), c02 = (m12 * m33) - (m32 * m13), c03 = (m12 * m23) - (m22 * m13);
+    const float c04 = (m21 * m33) - (m31 * m23), c06 = (m11 * m33) - (m31 * m13), c07 = (m11 * m23) - (m21 * m13);
+    const float c08 = (m21 * m32) - (m31 * m22), c10 = (m11 * m32) - (m31 * m12), c11 = (m11 * m22) - (m21 * m12);
+    const float c12 = (m20 * m33) - (m30 * m23), c14 = (m10 * m33) - (m30 * m13), c15 = (m10 * m23) - (m20 * m13);
+    const float c16 = (m20 * m32) - (m30 * m22), c18 = (m10 * m32) - (m30 * m12), c19 = (m10 * m22) - (m20 * m12);
+    const float c20 = (m20 * m31) - (m30 * m21), c22 = (m10 * m31) - (m30 * m11), c23 = (m10 * m21) - (m20 * m11);
+    const float f0[4] = {c00, c00, c02, c03}, f1[4] = {c04, c04, c06, c07}, f2[4] = {c08, c08, c10, c11};
+    const float f3[4] = {c12, c12, c14, c15}, f4[4] = {c16, c16, c18, c19}, f5[4] = {c20, c20, c22, c23};
+    const float v0[4] = {m10, m00, m00, m00}, v1[4] = {m11, m01, m01, m01}, v2[4] = {m12, m02, m02, m02}, v3[4] = {m13, m03, m03, m03};
+    const float sa[4] = {1.0f, -1.0f, 1.0f, -1.0f}, sb[4] = {-1.0f, 1.0f, -1.0f, 1.0f};
+    float ad[4][4];
+    for (int i = 0; i < 4; i++) {
+        ad[0][i] = ((v1[i] * f0[i]) - (v2[i] * f1[i]) + (v3[i] * f2[i])) * sa[i];
+        ad[1][i] = ((v0[i] * f0[i]) - (v2[i] * f3[i]) + (v3[i] * f4[i])) * sb[i];
+        ad[2][i] = ((v0[i] * f1[i]) - (v1[i] * f3[i]) + (v3[i] * f5[i])) * sa[i];
+        ad[3][i] = ((v0[i] * f2[i]) - (v1[i] * f4[i]) + (v2[i] * f5[i])) * sb[i];
+    }
+    const float d0 = m.c[0][0] * ad[0][0], d1 = m.c[0][1] * ad[1][0], d2 = m.c[0][2] * ad[2][0], d3 = m.c[0][3] * ad[3][0];
+    const float recip = 1.0f / (d0 + d1 + d2 + d3);
+    M4 r;
+    for (int col = 0; col < 4; col++)
+        for (int k = 0; k < 4; k++) r.c[col][k] = ad[col][k] * recip;
+    return r;
+}
+M4 m_rotation(const float axis[3], float angle) {  // matrix.rs:179-206
+    const float s = sinf(angle), co = cosf(angle);
+    const float mul = 1.0f - co;
+    const float xs = axis[0] * s, ys = axis[1] * s, zs = axis[2] * s;
+    const float xy = axis[0] * axis[1] * mul, xz = axis[0] * axis[2] * mul, yz = axis[1] * axis[2] * mul;
+    M4 m = m_identity();
+    m.c[0][0] = fmaf(axis[0] * axis[0], mul, co);
+    m.c[0][1] = xy + zs;
+    m.c[0][2] = xz - ys;
+    m.c[1][0] = xy - zs;
+    m.c[1][1] = fmaf(axis[1] * axis[1], mul, co);
+    m.c[1][2] = yz + xs;
+    m.c[2][0] = xz + ys;
+    m.c[2][1] = yz - xs;
+    m.c[2][2] = fmaf(axis[2] * axis[2], mul, co);
+    return m;
+}
+void m_point(const M4& m, const float p[3], float out[3]) {
+    for (int r = 0; r < 3; r++) out[r] = m.c[0][r] * p[0] + m.c[1][r] * p[1] + m.c[2][r] * p[2] + m.c[3][r] * 1.0f;
+}
+bool m_swaps_handedness(const M4& t) {  // parser/mod.rs:644-664
+    const float det = fmaf(t.c[0][0], fmaf(t.c[1][1], t.c[2][2], -(t.c[2][1] * t.c[1][2])),
+                           -(fmaf(t.c[1][0], fmaf(t.c[0][1], t.c[2][2], -(t.c[2][1] * t.c[0][2])),
+                                  -(t.c[2][0] * fmaf(t.c[0][1], t.c[1][2], -(t.c[1][1] * t.c[0][2]))))));
+    return det < 0.0f;
+}
+
+// ------------------------------------------------------------------ value parsing
+float parse_f32(const std::string& s) {
+    const char* b = s.c_str();
+    char* e = nullptr;
+    float v = strtof(b, &e);
+    if (e == b || *e != '\0') die("cannot parse float: '" + s + "'");
+    return v;
+}
+bool try_parse_f32(const std::string& s, float* out) {
+    const char* b = s.c_str();
+    char* e = nullptr;
+    float v = strtof(b, &e);
+    if (e == b || *e != '\0') return false;
+    *out = v;
+    return true;
+}
+int parse_i32(const std::string& s) {
+    const char* b = s.c_str();
+    char* e = nullptr;
+    long v = strtol(b, &e, 10);
+    if (e == b || *e != '\0') die("cannot parse integer: '" + s + "'");
+    return (int)v;
+}
+std::vector<std::string> split(const std::string& s, const std::string& sep) {
+    std::vector<std::string> out;
+    size_t b = 0;
+    for (;;) {
+        size_t e = s.find(sep, b);
+        if (e == std::string::npos) {
+            out.push_back(s.substr(b));
+            return out;
+        }
+        out.push_back(s.substr(b, e - b));
+        b = e + sep.size();
+    }
+}
+void parse_array3(const std::string& s, float out[3]) {  // parse_array: split(", ")
+    auto parts = split(s, ", ");
+    if (parts.size() != 3) die("expected 3 comma-separated values: '" + s + "'");
+    for (int i = 0; i < 3; i++) out[i] = parse_f32(parts[i]);
+}
+
+// ------------------------------------------------------------------ spectrum upsampling
+const float kD65[PT_CIE_N] = {PT_CIE_D65_VALUES};
+const double kXyz[PT_CIE_N][3] = {PT_CIE_XYZ_VALUES};
+
+// Jakob & Hanika 2019, "A Low-Dimensional Function Space for Efficient Spectral Upsampling": find c0,c1,c2 of
+// s(l) = S(c0 l^2 + c1 l + c2), S(x) = 1/2 + x / (2 sqrt(1+x^2)), whose colour under D65 matches `rgb` (sRGB
+// primaries) by Gauss-Newton on the CIELAB residual. The optimisation runs on l normalised to [0,1] and the
+// result is re-expressed for l in nm, the form rgb2spec.rs:8-54 reads out of srgb.coeffs.
+struct Rgb2SpecFitter {
+    double rgb_tbl[3][PT_CIE_N];
+    double white[3];
+    static constexpr double kXyzToRgb[3][3] = {{3.240479, -1.537150, -0.498535}, {-0.969256, 1.875991, 0.041556}, {0.055648, -0.204043, 1.057311}};
+    static constexpr double kRgbToXyz[3][3] = {{0.412453, 0.357580, 0.180423}, {0.212671, 0.715160, 0.072169}, {0.019334, 0.119193, 0.950227}};
+    Rgb2SpecFitter() {
+        white[0] = white[1] = white[2] = 0.0;
+        for (int i = 0; i < PT_CIE_N; i++) {
+            const double w = (i == 0 || i == PT_CIE_N - 1) ? 0.5 : 1.0;  // trapezoid, 1 nm
+            const double I = (double)kD65[i];
+            for (int k = 0; k < 3; k++) {
+                rgb_tbl[k][i] = 0.0;
+                for (int j = 0; j < 3; j++) rgb_tbl[k][i] += kXyzToRgb[k][j] * kXyz[i][j] * I * w;
+                white[k] += kXyz[i][k] * I * w;
+            }
+        }
+    }
+    void lab(double p[3]) const {
+        double xyz[3] = {0, 0, 0};
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) xyz[i] += p[j] * kRgbToXyz[i][j];
+        auto f = [](double t) {
+            const double d = 6.0 / 29.0;
+            return t > d * d * d ? cbrt(t) : t / (3.0 * d * d) + 4.0 / 29.0;
+        };
+        const double fx = f(xyz[0] / white[0]), fy = f(xyz[1] / white[1]), fz = f(xyz[2] / white[2]);
+        p[0] = 116.0 * fy - 16.0;
+        p[1] = 500.0 * (fx - fy);
+        p[2] = 200.0 * (fy - fz);
+    }
+    void residual(const double c[3], const double rgb[3], double r[3]) const {
+        double out[3] = {0, 0, 0};
+        for (int i = 0; i < PT_CIE_N; i++) {
+            const double l = (double)i / (double)(PT_CIE_N - 1);
+            const double x = (c[0] * l + c[1]) * l + c[2];
+            const double s = 0.5 * x / sqrt(x * x + 1.0) + 0.5;
+            for (int j = 0; j < 3; j++) out[j] += rgb_tbl[j][i] * s;
+        }
+        lab(out);
+        double t[3] = {rgb[0], rgb[1], rgb[2]};
+        lab(t);
+        for (int j = 0; j < 3; j++) r[j] = t[j] - out[j];
+    }
+    bool gauss_newton(const double rgb[3], double c[3]) const {
+        double r = 0.0;
+        for (int it = 0; it < 30; it++) {
+            double res[3], J[3][3];
+            residual(c, rgb, res);
+            for (int i = 0; i < 3; i++) {
+                const double eps = 1e-4;
+                double tmp[3] = {c[0], c[1], c[2]}, r0[3], r1[3];
+                tmp[i] -= eps;
+                residual(tmp, rgb, r0);
+                tmp[i] = c[i] + eps;
+                residual(tmp, rgb, r1);
+                for (int j = 0; j < 3; j++) J[j][i] = (r1[j] - r0[j]) / (2.0 * eps);
+            }
+            // solve J x = res (Cramer)
+            const double det = J[0][0] * (J[1][1] * J[2][2] - J[1][2] * J[2][1]) - J[0][1] * (J[1][0] * J[2][2] - J[1][2] * J[2][0]) +
+                               J[0][2] * (J[1][0] * J[2][1] - J[1][1] * J[2][0]);
+            if (det == 0.0 || !std::isfinite(det)) return false;
+            double x[3];
+            for (int k = 0; k < 3; k++) {
+                double M[3][3];
+                for (int a = 0; a < 3; a++)
+                    for (int b = 0; b < 3; b++) M[a][b] = (b == k) ? res[a] : J[a][b];
+                x[k] = (M[0][0] * (M[1][1] * M[2][2] - M[1][2] * M[2][1]) - M[0][1] * (M[1][0] * M[2][2] - M[1][2] * M[2][0]) +
+                        M[0][2] * (M[1][0] * M[2][1] - M[1][1] * M[2][0])) /
+                       det;
+            }
+            r = 0.0;
+            for (int j = 0; j < 3; j++) {
+                c[j] -= x[j];
+                r += res[j] * res[j];
+            }
+            const double mx = std::max(std::max(fabs(c[0]), fabs(c[1])), fabs(c[2]));
+            if (mx > 200.0)
+                for (int j = 0; j < 3; j++) c[j] *= 200.0 / mx;
+            if (r < 1e-6) break;
+        }
+        return r < 1e-2;
+    }
+    // rgb: components in [0,1] with max == 0.5 in practice (TristimulusSpectrum::new normalises by 2*max).
+    bool fit(const float rgb_in[3], float out[3]) const {
+        const double grey = std::max(std::max(rgb_in[0], rgb_in[1]), rgb_in[2]);
+        double c[3] = {0.0, 0.0, 0.0};
+        bool ok = true;
+        const int steps = 16;  // continuation from the grey of equal maximum to the target colour
+        for (int s = 1; s <= steps; s++) {
+            const double t = (double)s / steps;
+            const double rgb[3] = {grey + t * (rgb_in[0] - grey), grey + t * (rgb_in[1] - grey), grey + t * (rgb_in[2] - grey)};
+            ok = gauss_newton(rgb, c);
+        }
+        const double c0 = 360.0, c1 = 1.0 / (830.0 - 360.0);
+        const double A = c[0], B = c[1], C = c[2];
+        out[0] = (float)(A * (c1 * c1));
+        out[1] = (float)(B * c1 - 2.0 * A * c0 * (c1 * c1));
+        out[2] = (float)(C - B * c0 * c1 + A * (c0 * c1) * (c0 * c1));
+        return ok;
+    }
+};
+const Rgb2SpecFitter& fitter() {
+    static Rgb2SpecFitter f;
+    return f;
+}
+
+// TristimulusSpectrum::new (spectrum/mod.rs:272-302)
+bool rgb_to_spectrum(const float rgb_in[3], ptgpu_spectrum* out) {
+    float scale = fmaxf(fmaxf(rgb_in[0], rgb_in[1]), rgb_in[2]);
+    if (!std::isfinite(scale)) return false;
+    out->c0 = out->c1 = out->c2 = 0.0f;
+    out->scale = scale;
+    if (scale == 0.0f) return true;
+    scale *= 2.0f;
+    const float rgb[3] = {rgb_in[0] / scale, rgb_in[1] / scale, rgb_in[2] / scale};
+    out->scale = scale;
+    if (rgb[0] == rgb[1] && rgb[1] == rgb[2]) {
+        const float d = rgb[0] * (1.0f - rgb[0]);
+        out->c2 = (rgb[0] - 0.5f) / (d * d);
+        return true;
+    }
+    float c[3];
+    const float clamped[3] = {fminf(fmaxf(rgb[0], 0.0f), 1.0f), fminf(fmaxf(rgb[1], 0.0f), 1.0f), fminf(fmaxf(rgb[2], 0.0f), 1.0f)};
+    if (!fitter().fit(clamped, c)) return false;
+    out->c0 = c[0];
+    out->c1 = c[1];
+    out->c2 = c[2];
+    return true;
+}
+
+// ------------------------------------------------------------------ mesh files
+struct MeshData {
+    std::vector<float> points, normals;  // 3 per vertex
+    std::vector<uint32_t> tris;          // 3 per triangle
+};
+
+std::string read_file(const std::string& path) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f) die("File not found: " + path);
+    std::ostringstream ss;
+    ss << f.rdbuf();
+    return ss.str();
+}
+
+// parse_ply (parser/mod.rs:1173-1256): vertex {x,y,z[,nx,ny,nz]} floats + face lists; ascii or binary LE.
+MeshData parse_ply(const std::string& data) {
+    size_t pos = 0;
+    auto line = [&]() {
+        size_t e = data.find('\n', pos);
+        if (e == std::string::npos) die("ply: truncated header");
+        std::string l = data.substr(pos, e - pos);
+        pos = e + 1;
+        if (!l.empty() && l.back() == '\r') l.pop_back();
+        return l;
+    };
+    if (line() != "ply") die("ply: bad magic");
+    bool binary = false;
+    struct Prop {
+        std::string name, type, count_type;
+        bool list;
+    };
+    struct Elem {
+        std::string name;
+        size_t count;
+        std::vector<Prop> props;
+    };
+    std::vector<Elem> elems;
+    for (;;) {
+        std::istringstream ls(line());
+        std::string w;
+        ls >> w;
+        if (w == "format") {
+            std::string f;
+            ls >> f;
+            if (f == "binary_little_endian") binary = true;
+            else if (f == "ascii") binary = false;
+            else die("ply: unsupported format " + f);
+        } else if (w == "element") {
+            Elem e;
+            ls >> e.name >> e.count;
+            elems.push_back(e);
+        } else if (w == "property") {
+            if (elems.empty()) die("ply: property before element");
+            Prop p;
+            std::string t;
+            ls >> t;
+            if (t == "list") {
+                p.list = true;
+                ls >> p.count_type >> p.type >> p.name;
+            } else {
+                p.list = false;
+                p.type = t;
+                ls >> p.name;
+            }
+            elems.back().props.push_back(p);
+        } else if (w == "end_header")
+            break;
+    }
+    auto type_size = [](const std::string& t) -> size_t {
+        if (t == "char" || t == "uchar" || t == "int8" || t == "uint8") return 1;
+        if (t == "short" || t == "ushort" || t == "int16" || t == "uint16") return 2;
+        if (t == "int" || t == "uint" || t == "float" || t == "int32" || t == "uint32" || t == "float32") return 4;
+        if (t == "double" || t == "float64") return 8;
+        die("ply: unknown type " + t);
+    };
+    std::istringstream ascii(binary ? std::string() : data.substr(pos));
+    auto read_num = [&](const std::string& t) -> double {
+        if (!binary) {
+            double v;
+            if (!(ascii >> v)) die("ply: truncated ascii payload");
+            return v;
+        }
+        const size_t n = type_size(t);
+        if (pos + n > data.size()) die("ply: truncated payload");
+        const unsigned char* b = (const unsigned char*)data.data() + pos;
+        pos += n;
+        if (t == "float" || t == "float32") {
+            float f;
+            memcpy(&f, b, 4);
+            return f;
+        }
+        if (t == "double" || t == "float64") {
+            double d;
+            memcpy(&d, b, 8);
+            return d;
+        }
+        if (t == "uchar" || t == "uint8") return b[0];
+        if (t == "char" || t == "int8") return (signed char)b[0];
+        if (t == "ushort" || t == "uint16") {
+            uint16_t v;
+            memcpy(&v, b, 2);
+            return v;
+        }
+        if (t == "short" || t == "int16") {
+            int16_t v;
+            memcpy(&v, b, 2);
+            return v;
+        }
+        if (t == "uint" || t == "uint32") {
+            uint32_t v;
+            memcpy(&v, b, 4);
+            return v;
+        }
+        int32_t v;
+        memcpy(&v, b, 4);
+        return v;
+    };
+    MeshData m;
+    bool has_n = false;
+    for (auto& e : elems) {
+        if (e.name == "vertex") {
+            for (size_t i = 0; i < e.count; i++) {
+                float p[3] = {0, 0, 0}, n[3] = {0, 0, 0};
+                for (auto& pr : e.props) {
+                    if (pr.list) die("ply: list property on vertex");
+                    const float v = (float)read_num(pr.type);
+                    if (pr.name == "x") p[0] = v;
+                    else if (pr.name == "y") p[1] = v;
+                    else if (pr.name == "z") p[2] = v;
+                    else if (pr.name == "nx") n[0] = v, has_n = true;
+                    else if (pr.name == "ny") n[1] = v, has_n = true;
+                    else if (pr.name == "nz") n[2] = v, has_n = true;
+                    else die("Vertex: Unexpected key/value combination: key: " + pr.name);
+                }
+                m.points.insert(m.points.end(), p, p + 3);
+                m.normals.insert(m.normals.end(), n, n + 3);
+            }
+        } else if (e.name == "face") {
+            for (size_t i = 0; i < e.count; i++)
+                for (auto& pr : e.props) {
+                    if (!pr.list || (pr.name != "vertex_index" && pr.name != "vertex_indices")) die("Face: Unexpected key/value combination: key: " + pr.name);
+                    const int cnt = (int)read_num(pr.count_type);
+                    if (cnt != 3) die("ply: non-triangle face");
+                    for (int k = 0; k < 3; k++) m.tris.push_back((uint32_t)read_num(pr.type));
+                }
+        } else
+            die("Enexpeced element!");
+    }
+    (void)has_n;
+    // parser/mod.rs:1242-1244: normals are dropped when the FIRST one is the zero vector
+    if (m.normals.size() >= 3 && m.normals[0] == 0.0f && m.normals[1] == 0.0f && m.normals[2] == 0.0f) m.normals.clear();
+    return m;
+}
+
+// parse_obj (parser/mod.rs:1258-1303): one object/group of triangles "f p/t/n p/t/n p/t/n"; winding fixed so that
+// the geometric normal agrees with the summed vertex normals.
+MeshData parse_obj(const std::string& path) {
+    std::istringstream in(read_file(path));
+    MeshData m;
+    std::string l;
+    struct Idx {
+        long p, n;
+    };
+    auto cross_tri = [&](const float* p0, const float* p1, const float* p2, float out[3]) {  // geom::triangle_cross
+        const float a[3] = {p0[0] - p1[0], p0[1] - p1[1], p0[2] - p1[2]}, b[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]};
+        out[0] = a[1] * b[2] - a[2] * b[1];
+        out[1] = a[2] * b[0] - a[0] * b[2];
+        out[2] = a[0] * b[1] - a[1] * b[0];
+    };
+    std::vector<std::array<Idx, 3>> faces;
+    while (std::getline(in, l)) {
+        std::istringstream ls(l);
+        std::string w;
+        ls >> w;
+        if (w == "v") {
+            float p[3];
+            ls >> p[0] >> p[1] >> p[2];
+            m.points.insert(m.points.end(), p, p + 3);
+        } else if (w == "vn") {
+            float n[3];
+            ls >> n[0] >> n[1] >> n[2];
+            m.normals.insert(m.normals.end(), n, n + 3);
+        } else if (w == "f") {
+            std::vector<Idx> poly;
+            std::string tok;
+            while (ls >> tok) {
+                Idx ix{0, 0};
+                auto parts = split(tok, "/");
+                ix.p = strtol(parts[0].c_str(), nullptr, 10);
+                if (parts.size() >= 3 && !parts[2].empty()) ix.n = strtol(parts[2].c_str(), nullptr, 10);
+                poly.push_back(ix);
+            }
+            if (poly.size() != 3) die("bad length: " + std::to_string(poly.size()));
+            faces.push_back({poly[0], poly[1], poly[2]});
+        }
+    }
+    const long np = (long)m.points.size() / 3, nn = (long)m.normals.size() / 3;
+    if (!(nn == np || nn == 0)) die("obj: normal count differs from position count");
+    for (auto& f : faces) {
+        uint32_t tri[3];
+        long ni[3];
+        for (int k = 0; k < 3; k++) {
+            long p = f[k].p > 0 ? f[k].p - 1 : np + f[k].p;
+            if (p < 0 || p >= np) die("obj: position index out of range");
+            tri[k] = (uint32_t)p;
+            ni[k] = f[k].n > 0 ? f[k].n - 1 : (f[k].n < 0 ? nn + f[k].n : -1);
+        }
+        if (ni[0] >= 0 && ni[1] >= 0 && ni[2] >= 0) {
+            for (int k = 0; k < 3; k++)
+                if (ni[k] != (long)tri[k]) die("obj: position and normal indices differ");
+            float ns[3];
+            for (int c = 0; c < 3; c++) ns[c] = m.normals[3 * ni[0] + c] + m.normals[3 * ni[1] + c] + m.normals[3 * ni[2] + c];
+            float ng[3];
+            cross_tri(&m.points[3 * tri[0]], &m.points[3 * tri[1]], &m.points[3 * tri[2]], ng);
+            if (ng[0] * ns[0] + ng[1] * ns[1] + ng[2] * ns[2] < 0.0f) std::swap(tri[0], tri[2]);
+        }
+        m.tris.insert(m.tris.end(), tri, tri + 3);
+    }
+    return m;
+}
+
+// ------------------------------------------------------------------ scene_v3.xml
+using Defaults = std::map<std::string, std::string>;
+
+struct Loader {
+    Defaults defaults, overrides;
+    std::string root, data_dir;
+
+    const std::string* attr_checked(const XmlNode& n, const char* k) const {  // parser/mod.rs:1143-1156
+        const std::string* a = n.attr(k);
+        if (!a) return nullptr;
+        if (!a->empty() && (*a)[0] == '$') {
+            auto it = defaults.find(a->substr(1));
+            if (it == defaults.end()) die("undefined default: " + *a);
+            return &it->second;
+        }
+        return a;
+    }
+    const std::string& attr(const XmlNode& n, const char* k) const {
+        const std::string* a = attr_checked(n, k);
+        if (!a) die(std::string("attr not found: ") + k + " in node: " + n.tag);
+        return *a;
+    }
+    void vector3(const XmlNode& n, float dflt, float out[3]) const {  // parse_vector
+        if (const std::string* v = attr_checked(n, "value")) {
+            parse_array3(*v, out);
+            return;
+        }
+        const char* keys[3] = {"x", "y", "z"};
+        for (int i = 0; i < 3; i++) {
+            const std::string* a = attr_checked(n, keys[i]);
+            out[i] = a ? parse_f32(*a) : dflt;
+        }
+    }
+    M4 transform(const XmlNode& n) const {  // parse_transform (parser/mod.rs:666-695)
+        M4 t = m_identity();
+        for (auto& ch : n.children) {
+            const XmlNode& c = *ch;
+            if (c.tag == "matrix") {
+                auto parts = split(attr(c, "value"), " ");
+                if (parts.size() != 16) die("matrix needs 16 values");
+                float r[16];
+                for (int i = 0; i < 16; i++) r[i] = parse_f32(parts[i]);
+                t = m_from_rows(r);
+            } else if (c.tag == "scale") {
+                float s[3];
+                float f;
+                const std::string* v = attr_checked(c, "value");
+                if (v && try_parse_f32(*v, &f)) s[0] = s[1] = s[2] = f;
+                else vector3(c, 1.0f, s);
+                M4 m = m_identity();
+                m.c[0][0] = s[0];
+                m.c[1][1] = s[1];
+                m.c[2][2] = s[2];
+                t = m_mul(m, t);
+            } else if (c.tag == "translate") {
+                float v[3];
+                vector3(c, 0.0f, v);
+                M4 m = m_identity();
+                m.c[3][0] = v[0];
+                m.c[3][1] = v[1];
+                m.c[3][2] = v[2];
+                t = m_mul(m, t);
+            } else if (c.tag == "rotate") {
+                float axis[3];
+                const char* keys[3] = {"x", "y", "z"};
+                for (int i = 0; i < 3; i++) {
+                    const std::string* a = attr_checked(c, keys[i]);
+                    axis[i] = a ? parse_f32(*a) : 0.0f;
+                }
+                const float angle = parse_f32(attr(c, "angle"));
+                t = m_mul(m_rotation(axis, angle * (3.14159265358979323846f / 180.0f)), t);
+            } else if (c.tag == "lookat") {
+                float target[3], origin[3], up[3];
+                parse_array3(attr(c, "target"), target);
+                parse_array3(attr(c, "origin"), origin);
+                parse_array3(attr(c, "up"), up);
+                auto norm = [](float v[3]) {
+                    const float inv = 1.0f / sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+                    v[0] *= inv;
+                    v[1] *= inv;
+                    v[2] *= inv;
+                };
+                auto cross = [](const float a[3], const float b[3], float o[3]) {
+                    o[0] = a[1] * b[2] - a[2] * b[1];
+                    o[1] = a[2] * b[0] - a[0] * b[2];
+                    o[2] = a[0] * b[1] - a[1] * b[0];
+                };
+                float fwd[3] = {target[0] - origin[0], target[1] - origin[1], target[2] - origin[2]};
+                norm(fwd);
+                float left[3];
+                cross(up, fwd, left);
+                norm(left);
+                float alt_up[3];
+                cross(fwd, left, alt_up);
+                norm(alt_up);
+                const float r[16] = {left[0], alt_up[0], fwd[0], origin[0], left[1], alt_up[1], fwd[1], origin[1],
+                                     left[2], alt_up[2], fwd[2], origin[2], 0.0f,    0.0f,      0.0f,   1.0f};
+                t = m_mul(m_from_rows(r), t);
+            }
+        }
+        return t;
+    }
+};
+
+struct BsdfDecl {
+    std::string id;
+    int kind;  // PTGPU_MAT_*
+    float roughness = 0.1f;
+    float rgb0[3] = {0.5f, 0.5f, 0.5f};                       // reflectance | eta (rgb)
+    float rgb1[3] = {3.91295f, 2.45285f, 2.14219f};           // k
+    float ext_ior = 1.0f, int_ior = 1.5f;
+};
+
+}  // namespace
+
+struct pthost_scene {
+    std::vector<MeshData> mesh_data;
+    std::vector<ptgpu_mesh> meshes;
+    std::vector<ptgpu_material> materials;
+    ptgpu_scene_desc scene{};
+    ptgpu_camera_desc camera{};
+    ptgpu_integrator_desc integrator{};
+    uint32_t spp = 0;
+    std::string output_name;
+};
+
+namespace {
+
+void parse_bsdf(const Loader& L, const XmlNode& n, BsdfDecl& b) {  // parse_bsdf (parser/mod.rs:426-472)
+    const std::string& type = L.attr(n, "type");
+    if (type == "twosided") {
+        if (n.children.empty() || n.children[0]->tag != "bsdf") die("twosided needs a bsdf child");
+        parse_bsdf(L, *n.children[0], b);
+    } else if (type == "diffuse") {
+        b.kind = PTGPU_MAT_LAMBERTIAN;
+        for (auto& c : n.children)
+            if (c->tag == "rgb" && L.attr(*c, "name") == "reflectance") parse_array3(L.attr(*c, "value"), b.rgb0);
+    } else if (type == "roughconductor") {
+        b.kind = PTGPU_MAT_CONDUCTOR;
+        b.rgb0[0] = 0.200438f;
+        b.rgb0[1] = 0.924033f;
+        b.rgb0[2] = 1.10221f;
+        for (auto& c : n.children) {
+            if (c->tag == "float" && L.attr(*c, "name") == "alpha") b.roughness = parse_f32(L.attr(*c, "value"));
+            else if (c->tag == "rgb" && L.attr(*c, "name") == "eta") parse_array3(L.attr(*c, "value"), b.rgb0);
+            else if (c->tag == "rgb" && L.attr(*c, "name") == "k") parse_array3(L.attr(*c, "value"), b.rgb1);
+        }
+    } else if (type == "dielectric") {
+        b.kind = PTGPU_MAT_DIELECTRIC;
+        for (auto& c : n.children) {
+            if (c->tag == "float" && L.attr(*c, "name") == "int_ior") b.int_ior = parse_f32(L.attr(*c, "value"));
+            else if (c->tag == "float" && L.attr(*c, "name") == "ext_ior") b.ext_ior = parse_f32(L.attr(*c, "value"));
+        }
+    } else
+        die("unknown bsdf type: " + type);
+}
+
+int parse_mode(const std::string& m) {
+    if (m == "PT") return PTGPU_MODE_PT;
+    if (m == "NEE") return PTGPU_MODE_NEE;
+    if (m == "MIS") return PTGPU_MODE_MIS;
+    die("unknown integrator mode: " + m);
+}
+
+pthost_scene* load_scene(const char* collection, const char* name, const char* overrides, const char* data_dir) {
+    Loader L;
+    L.root = std::string(collection) + "/" + name;
+    if (data_dir) L.data_dir = data_dir;
+    else {
+        Dl_info info;
+        if (dladdr((void*)&load_scene, &info) && info.dli_fname) {
+            std::string p = info.dli_fname;
+            size_t s = p.rfind('/');
+            L.data_dir = (s == std::string::npos ? std::string(".") : p.substr(0, s)) + "/../data";
+        } else
+            L.data_dir = "path-tracer_amd/data";
+    }
+    if (overrides)
+        for (auto& kv : split(overrides, ";")) {
+            if (kv.empty()) continue;
+            size_t eq = kv.find('=');
+            if (eq == std::string::npos) die("override must be key=value: " + kv);
+            L.overrides[kv.substr(0, eq)] = kv.substr(eq + 1);
+        }
+    const std::string content = read_file(L.root + "/scene_v3.xml");
+    XmlParser xp(content);
+    std::unique_ptr<XmlNode> doc = xp.document();
+    if (doc->tag != "scene") die("root element must be <scene>");
+    const std::string* ver = doc->attr("version");
+    if (!ver || *ver != "3.0.0") die("scene version must be 3.0.0");
+    auto S = std::make_unique<pthost_scene>();
+    const std::string* outn = doc->attr("output");
+    S->output_name = outn ? *outn : "out.png";
+
+    // defaults (parser/mod.rs:1059-1121, 1005-1044)
+    ptgpu_integrator_desc integ{};
+    integ.kind = PTGPU_INTEGRATOR_PATH;
+    integ.max_depth = 0xffffffffu;  // usize::MAX
+    integ.mode = PTGPU_MODE_MIS;
+    integ.spatial_threshold = 1000.0f;
+    integ.directional_threshold = 0.1f;
+    integ.spatial_filter = PTGPU_FILTER_STOCHASTIC;
+    integ.directional_filter = PTGPU_FILTER_BOX;
+    float fov = 30.0f;
+    int width = 128, height = 128, sample_count = 0;
+    M4 cam_to_world = m_identity();
+    std::vector<BsdfDecl> bsdfs;
+    struct ShapeDecl {
+        MeshData mesh;
+        M4 transform;
+        bool has_emitter = false;
+        float radiance[3] = {1.0f, 1.0f, 1.0f};
+        std::vector<std::string> refs;
+    };
+    std::vector<ShapeDecl> shapes;
+
+    for (auto& chp : doc->children) {
+        const XmlNode& n = *chp;
+        if (n.tag == "default") {
+            const std::string& k = L.attr(n, "name");
+            auto ov = L.overrides.find(k);
+            L.defaults[k] = ov != L.overrides.end() ? ov->second : L.attr(n, "value");
+        } else if (n.tag == "integrator") {
+            const std::string& type = L.attr(n, "type");
+            if (type == "path") {
+                integ.kind = PTGPU_INTEGRATOR_PATH;
+                integ.max_depth = 0xffffffffu;
+            } else if (type == "lightpath") {
+                integ.kind = PTGPU_INTEGRATOR_LIGHTPATH;
+                integ.max_depth = 0xffffffffu;
+            } else if (type == "guided") {
+                integ.kind = PTGPU_INTEGRATOR_GUIDED;
+                integ.max_depth = 16;
+            } else
+                die("unkown integrator type: " + type);
+            for (auto& c : n.children) {
+                if (c->tag == "integer" && L.attr(*c, "name") == "max_depth") integ.max_depth = (uint32_t)parse_i32(L.attr(*c, "value"));
+                else if (c->tag == "string" && L.attr(*c, "name") == "mode" && integ.kind != PTGPU_INTEGRATOR_LIGHTPATH) integ.mode = parse_mode(L.attr(*c, "value"));
+                else if (c->tag == "float" && L.attr(*c, "name") == "spatial_threashold" && integ.kind == PTGPU_INTEGRATOR_GUIDED)
+                    integ.spatial_threshold = parse_f32(L.attr(*c, "value"));
+            }
+        } else if (n.tag == "sensor") {
+            if (L.attr(n, "type") != "perspective") die("sensor type must be perspective");
+            for (auto& c : n.children) {
+                if (c->tag == "float" && L.attr(*c, "name") == "fov") fov = parse_f32(L.attr(*c, "value"));
+                else if (c->tag == "transform" && L.attr(*c, "name") == "to_world") cam_to_world = L.transform(*c);
+                else if (c->tag == "sampler") {
+                    for (auto& cc : c->children)
+                        if (cc->tag == "integer" && L.attr(*cc, "name") == "sample_count") sample_count = parse_i32(L.attr(*cc, "value"));
+                } else if (c->tag == "film") {
+                    for (auto& cc : c->children) {
+                        if (cc->tag == "integer" && L.attr(*cc, "name") == "width") width = parse_i32(L.attr(*cc, "value"));
+                        else if (cc->tag == "integer" && L.attr(*cc, "name") == "height") height = parse_i32(L.attr(*cc, "value"));
+                    }
+                }
+            }
+        } else if (n.tag == "bsdf") {
+            BsdfDecl b;
+            b.id = L.attr(n, "id");
+            b.kind = PTGPU_MAT_LAMBERTIAN;
+            parse_bsdf(L, n, b);
+            bsdfs.push_back(b);
+        } else if (n.tag == "shape") {  // parse_shape (parser/mod.rs:532-642)
+            ShapeDecl sh;
+            sh.transform = m_identity();
+            const std::string& type = L.attr(n, "type");
+            std::string filename;
+            bool face_normals = false;
+            if (type == "rectangle") {
+                sh.mesh.points = {-1, -1, 0, 1, -1, 0, 1, 1, 0, -1, 1, 0};
+                sh.mesh.tris = {2, 1, 0, 0, 3, 2};
+            } else if (type == "cube") {
+                sh.mesh.points = {-1, -1, -1, 1, -1, -1, 1, -1, 1, -1, -1, 1, -1, 1, -1, 1, 1, -1, 1, 1, 1, -1, 1, 1};
+                sh.mesh.tris = {2, 1, 0, 0, 3, 2, 0, 1, 5, 5, 4, 0, 1, 2, 6, 6, 5, 1, 2, 3, 7, 7, 6, 2, 3, 0, 4, 4, 7, 3, 4, 5, 6, 6, 7, 4};
+            } else if (type == "sphere") {
+                sh.mesh = parse_ply(read_file(L.data_dir + "/icosphere_6.ply"));
+            } else if (type == "obj" || type == "ply") {
+            } else if (type == "serialized") {
+                die("shape type 'serialized' is not supported by this host (SURVEY.md §8f-1)");
+            } else
+                die("unknown shape type: " + type);
+            for (auto& c : n.children) {
+                if (c->tag == "transform" && L.attr(*c, "name") == "to_world") sh.transform = L.transform(*c);
+                else if (c->tag == "emitter") {
+                    const std::string& et = L.attr(*c, "type");
+                    if (et != "area") die("unknown emitter type on a shape: " + et);
+                    sh.has_emitter = true;
+                    for (auto& cc : c->children)
+                        if (cc->tag == "rgb" && L.attr(*cc, "name") == "radiance") parse_array3(L.attr(*cc, "value"), sh.radiance);
+                } else if (c->tag == "ref") sh.refs.push_back(L.attr(*c, "id"));
+                else if (c->tag == "string" && L.attr(*c, "name") == "filename" && (type == "obj" || type == "ply")) filename = L.attr(*c, "value");
+                else if (c->tag == "boolean" && L.attr(*c, "name") == "face_normals" && type == "obj") face_normals = L.attr(*c, "value") == "true";
+                else if (type == "sphere" && c->tag == "float" && L.attr(*c, "name") == "radius") {
+                    const float r = parse_f32(L.attr(*c, "value"));
+                    for (float& v : sh.mesh.points) v *= r;
+                } else if (type == "sphere" && c->tag == "point" && L.attr(*c, "name") == "center") {
+                    const float ctr[3] = {parse_f32(L.attr(*c, "x")), parse_f32(L.attr(*c, "y")), parse_f32(L.attr(*c, "z"))};
+                    for (size_t i = 0; i < sh.mesh.points.size(); i++) sh.mesh.points[i] += ctr[i % 3];
+                }
+            }
+            if (type == "obj") {
+                sh.mesh = parse_obj(L.root + "/" + filename);
+                if (face_normals) sh.mesh.normals.clear();
+            } else if (type == "ply") {
+                sh.mesh = parse_ply(read_file(L.root + "/" + filename));
+            }
+            shapes.push_back(std::move(sh));
+        } else if (n.tag == "emitter") {
+            die("scene-level emitters (sunsky) are out of scope: the reference's envmap path is unfinished (README.md:4)");
+        }
+    }
+
+    // materials: every parsed bsdf, in document order (parser/mod.rs:104-123)
+    for (auto& b : bsdfs) {
+        ptgpu_material m{};
+        m.kind = b.kind;
+        m.roughness = b.roughness;
+        bool ok = true;
+        if (b.kind == PTGPU_MAT_DIELECTRIC) {
+            const float e = b.int_ior / b.ext_ior;
+            const float rgb[3] = {e, e, e};
+            ok = rgb_to_spectrum(rgb, &m.s0);
+        } else {
+            ok = rgb_to_spectrum(b.rgb0, &m.s0);
+            if (b.kind == PTGPU_MAT_CONDUCTOR) ok = ok && rgb_to_spectrum(b.rgb1, &m.s1);
+        }
+        if (!ok) die("spectrum upsampling failed for bsdf " + b.id);
+        S->materials.push_back(m);
+    }
+    // meshes (parser/mod.rs:159-245)
+    for (auto& sh : shapes) {
+        MeshData md;
+        const M4& t = sh.transform;
+        md.points.resize(sh.mesh.points.size());
+        for (size_t i = 0; i + 2 < sh.mesh.points.size(); i += 3) m_point(t, &sh.mesh.points[i], &md.points[i]);
+        if (!sh.mesh.normals.empty()) {
+            const M4 inv = m_inverse(t);
+            md.normals.resize(sh.mesh.normals.size());
+            for (size_t i = 0; i + 2 < sh.mesh.normals.size(); i += 3) {
+                const float* nn = &sh.mesh.normals[i];
+                for (int r = 0; r < 3; r++) md.normals[i + r] = inv.c[0][r] * nn[0] + inv.c[1][r] * nn[1] + inv.c[2][r] * nn[2];
+            }
+        }
+        md.tris = sh.mesh.tris;
+        if (m_swaps_handedness(t))
+            for (size_t i = 0; i + 2 < md.tris.size(); i += 3) std::swap(md.tris[i], md.tris[i + 2]);
+        S->mesh_data.push_back(std::move(md));
+    }
+    for (size_t i = 0; i < shapes.size(); i++) {
+        const auto& sh = shapes[i];
+        const MeshData& md = S->mesh_data[i];
+        ptgpu_mesh m{};
+        m.points = md.points.data();
+        m.normals = md.normals.empty() ? nullptr : md.normals.data();
+        m.triangles = md.tris.data();
+        m.n_points = (uint32_t)(md.points.size() / 3);
+        m.n_triangles = (uint32_t)(md.tris.size() / 3);
+        m.material_index = -1;
+        for (auto& r : sh.refs) {
+            bool found = false;
+            for (size_t b = 0; b < bsdfs.size(); b++)
+                if (bsdfs[b].id == r) {
+                    m.material_index = (int32_t)b;
+                    found = true;
+                    break;
+                }
+            if (found) break;
+        }
+        const float zero[3] = {0.0f, 0.0f, 0.0f};
+        const float* e = sh.has_emitter ? sh.radiance : zero;
+        m.emissive = (e[0] != 0.0f || e[1] != 0.0f || e[2] != 0.0f) ? 1 : 0;
+        if (!rgb_to_spectrum(e, &m.emission)) die("spectrum upsampling failed for an emitter");
+        S->meshes.push_back(m);
+    }
+    S->scene.meshes = S->meshes.data();
+    S->scene.materials = S->materials.data();
+    S->scene.n_meshes = (uint32_t)S->meshes.size();
+    S->scene.n_materials = (uint32_t)S->materials.size();
+    const M4 w2c = m_inverse(cam_to_world);
+    for (int r = 0; r < 4; r++)
+        for (int c = 0; c < 4; c++) S->camera.world_to_camera[4 * r + c] = w2c.c[c][r];
+    S->camera.fov_deg = fov;
+    if (width <= 0 || height <= 0) die("film size must be positive");
+    S->camera.resx = (uint32_t)width;
+    S->camera.resy = (uint32_t)height;
+    S->spp = (uint32_t)(sample_count < 0 ? 0 : sample_count);
+    S->integrator = integ;
+    return S.release();
+}
+
+// ------------------------------------------------------------------ PNG (stored deflate blocks) / PFM
+uint32_t crc32_update(uint32_t crc, const unsigned char* p, size_t n) {
+    static uint32_t table[256];
+    static bool init = false;
+    if (!init) {
+        for (uint32_t i = 0; i < 256; i++) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; k++) c = (c & 1) ? 0xedb88320u ^ (c >> 1) : c >> 1;
+            table[i] = c;
+        }
+        init = true;
+    }
+    for (size_t i = 0; i < n; i++) crc = table[(crc ^ p[i]) & 0xff] ^ (crc >> 8);
+    return crc;
+}
+void put_be32(std::vector<unsigned char>& v, uint32_t x) {
+    v.push_back(x >> 24);
+    v.push_back(x >> 16);
+    v.push_back(x >> 8);
+    v.push_back(x);
+}
+void png_chunk(std::vector<unsigned char>& out, const char* type, const std::vector<unsigned char>& data) {
+    put_be32(out, (uint32_t)data.size());
+    std::vector<unsigned char> td(type, type + 4);
+    td.insert(td.end(), data.begin(), data.end());
+    out.insert(out.end(), td.begin(), td.end());
+    put_be32(out, crc32_update(0xffffffffu, td.data(), td.size()) ^ 0xffffffffu);
+}
+bool write_png_rgba(const std::string& path, const std::vector<unsigned char>& rgba, uint32_t w, uint32_t h) {
+    std::vector<unsigned char> raw;
+    raw.reserve((size_t)h * (4 * w + 1));
+    for (uint32_t y = 0; y < h; y++) {
+        raw.push_back(0);
+        raw.insert(raw.end(), rgba.begin() + (size_t)y * 4 * w, rgba.begin() + (size_t)(y + 1) * 4 * w);
+    }
+    std::vector<unsigned char> z = {0x78, 0x01};
+    uint32_t a = 1, b = 0;
+    for (unsigned char c : raw) {
+        a = (a + c) % 65521u;
+        b = (b + a) % 65521u;
+    }
+    for (size_t off = 0; off < raw.size() || off == 0; off += 65535) {
+        const size_t n = std::min<size_t>(65535, raw.size() - off);
+        z.push_back(off + n >= raw.size() ? 1 : 0);
+        z.push_back(n & 0xff);
+        z.push_back(n >> 8);
+        z.push_back(~n & 0xff);
+        z.push_back((~n >> 8) & 0xff);
+        z.insert(z.end(), raw.begin() + off, raw.begin() + off + n);
+        if (raw.empty()) break;
+    }
+    put_be32(z, (b << 16) | a);
+    std::vector<unsigned char> out = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+    std::vector<unsigned char> ihdr;
+    put_be32(ihdr, w);
+    put_be32(ihdr, h);
+    ihdr.insert(ihdr.end(), {8, 6, 0, 0, 0});
+    png_chunk(out, "IHDR", ihdr);
+    png_chunk(out, "IDAT", z);
+    png_chunk(out, "IEND", {});
+    FILE* f = fopen(path.c_str(), "wb");
+    if (!f) return false;
+    const bool ok = fwrite(out.data(), 1, out.size(), f) == out.size();
+    fclose(f);
+    return ok;
+}
+
+template <class F>
+auto guarded(F f, decltype(f()) on_error) -> decltype(f()) {
+    try {
+        return f();
+    } catch (const Error& e) {
+        g_err = e.msg;
+    } catch (const std::exception& e) {
+        g_err = e.what();
+    }
+    return on_error;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* pthost_last_error(void) { return g_err.c_str(); }
+
+pthost_scene* pthost_scene_load(const char* collection, const char* name, const char* overrides, const char* data_dir) {
+    if (!collection || !name) {
+        g_err = "scene_load: NULL argument";
+        return nullptr;
+    }
+    return guarded([&]() { return load_scene(collection, name, overrides, data_dir); }, (pthost_scene*)nullptr);
+}
+void pthost_scene_free(pthost_scene* s) { delete s; }
+const ptgpu_scene_desc* pthost_scene_desc(const pthost_scene* s) { return s ? &s->scene : nullptr; }
+const ptgpu_camera_desc* pthost_camera_desc(const pthost_scene* s) { return s ? &s->camera : nullptr; }
+const ptgpu_integrator_desc* pthost_integrator_desc(const pthost_scene* s) { return s ? &s->integrator : nullptr; }
+uint32_t pthost_spp(const pthost_scene* s) { return s ? s->spp : 0; }
+const char* pthost_output_name(const pthost_scene* s) { return s ? s->output_name.c_str() : ""; }
+
+int pthost_rgb_to_spectrum(const float rgb[3], ptgpu_spectrum* out) {
+    if (!rgb || !out) return -1;
+    return guarded([&]() { return rgb_to_spectrum(rgb, out) ? 0 : -1; }, -1);
+}
+
+int pthost_save_image(const double* film, uint32_t w, uint32_t h, double scale, int as_splats, const char* dir, const char* file_name) {
+    if (!film || !dir || !file_name || w == 0 || h == 0) return -1;
+    // Film::save_image (camera.rs:197-237): gamma 1/2.2 for splats, 1/2.4 for tile pixels, *255.999 truncated.
+    const double g = as_splats ? 1.0 / 2.2 : 1.0 / 2.4;
+    std::vector<unsigned char> data((size_t)w * h * 4);
+    for (size_t i = 0; i < (size_t)w * h; i++) {
+        for (int c = 0; c < 3; c++) {
+            double v = pow(film[3 * i + c] * scale, g);  // NaN (negative base) -> clamp keeps NaN -> `as u8` = 0
+            v = v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v);
+            const double q = v * 255.999;
+            data[4 * i + c] = (q != q) ? 0 : (unsigned char)q;
+        }
+        data[4 * i + 3] = 255;
+    }
+    mkdir(dir, 0777);
+    return write_png_rgba(std::string(dir) + "/" + file_name, data, w, h) ? 0 : -1;
+}
+
+int pthost_save_pfm(const double* film, uint32_t w, uint32_t h, double scale, const char* path) {
+    if (!film || !path) return -1;
+    FILE* f = fopen(path, "wb");
+    if (!f) return -1;
+    fprintf(f, "PF\n%u %u\n-1.0\n", w, h);
+    std::vector<float> row(3 * (size_t)w);
+    for (uint32_t y = 0; y < h; y++) {
+        const double* src = film + 3 * (size_t)w * (h - 1 - y);
+        for (size_t i = 0; i < row.size(); i++) row[i] = (float)(src[i] * scale);
+        fwrite(row.data(), 4, row.size(), f);
+    }
+    fclose(f);
+    return 0;
+}
+
+}  // extern "C"

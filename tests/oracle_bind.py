@@ -1,0 +1,110 @@
+"""ctypes binding of the CPU oracle (oracle/_build/liboracle.so). TEST INFRASTRUCTURE ONLY: imported by tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg, never by the product package."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+import numpy as np
+
+import path_tracer_amd as pt
+
+REPO = Path(__file__).resolve().parent.parent
+LIB = REPO / "oracle" / "_build" / "liboracle.so"
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not LIB.exists():
+            raise RuntimeError(f"{LIB} missing: run `make -C oracle`")
+        lib = C.CDLL(str(LIB))
+        lib.orc_scene_create.restype = C.c_void_p
+        lib.orc_scene_create.argtypes = [C.POINTER(pt.SceneDesc)]
+        lib.orc_scene_destroy.argtypes = [C.c_void_p]
+        lib.orc_scene_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_float)]
+        lib.orc_scene_bvh.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        lib.orc_trace_batch.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_uint32, C.c_void_p, C.POINTER(C.c_uint64)]
+        lib.orc_occluded_batch.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_uint32, C.POINTER(C.c_uint8)]
+        lib.orc_render.argtypes = [C.c_void_p, C.POINTER(pt.CameraDesc), C.POINTER(pt.IntegratorDesc), C.c_uint32, C.c_uint32, C.c_uint32,
+                                   C.c_int, C.c_uint32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+        lib.orc_fresnel.restype = C.c_float
+        lib.orc_fresnel.argtypes = [C.c_float, C.c_float]
+        lib.orc_complex_fresnel.restype = C.c_float
+        lib.orc_complex_fresnel.argtypes = [C.c_float, C.c_float, C.c_float]
+        _lib = lib
+    return _lib
+
+
+def fptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+class OracleScene:
+    def __init__(self, scene):
+        self.lib = load()
+        self.handle = self.lib.orc_scene_create(scene.pointer())
+        if not self.handle:
+            raise RuntimeError("orc_scene_create failed")
+        self._scene = scene
+
+    def close(self):
+        if self.handle:
+            self.lib.orc_scene_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def info(self):
+        nn, nt, ne = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        b = (C.c_float * 6)()
+        self.lib.orc_scene_info(self.handle, C.byref(nn), C.byref(nt), C.byref(ne), b)
+        return {"n_nodes": nn.value, "n_tris": nt.value, "n_emissive_tris": ne.value, "bounds": np.array(list(b), dtype=np.float32)}
+
+    def bvh(self):
+        i = self.info()
+        nodes = np.zeros((i["n_nodes"], 8), dtype=np.uint32)
+        leaf = np.zeros((i["n_tris"], 2), dtype=np.uint32)
+        self.lib.orc_scene_bvh(self.handle, nodes.ctypes.data_as(C.POINTER(C.c_uint32)), leaf.ctypes.data_as(C.POINTER(C.c_uint32)))
+        return nodes, leaf
+
+    def trace(self, rays, counters=False):
+        rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 7)
+        out = np.zeros(rays.shape[0], dtype=pt.HIT_DTYPE)
+        cnt = (C.c_uint64 * 2)()
+        self.lib.orc_trace_batch(self.handle, fptr(rays), rays.shape[0], out.ctypes.data_as(C.c_void_p), cnt)
+        return (out, (cnt[0], cnt[1])) if counters else out
+
+    def occluded(self, a, b):
+        a = np.ascontiguousarray(a, dtype=np.float32).reshape(-1, 3)
+        b = np.ascontiguousarray(b, dtype=np.float32).reshape(-1, 3)
+        out = np.zeros(a.shape[0], dtype=np.uint8)
+        self.lib.orc_occluded_batch(self.handle, fptr(a), fptr(b), a.shape[0], out.ctypes.data_as(C.POINTER(C.c_uint8)))
+        return out
+
+    def render(self, cam, integrator, spp, shard_index=0, shard_count=1, n_threads=0, max_waves=0):
+        """-> (film sums (H,W,3), film_scale, stats dict)"""
+        cam = pt.CameraDesc.from_buffer_copy(cam)
+        integ = pt.IntegratorDesc.from_buffer_copy(integrator)
+        film = np.zeros((cam.resy, cam.resx, 3), dtype=np.float64)
+        scale = C.c_double()
+        st = (C.c_uint64 * 8)()
+        rc = self.lib.orc_render(self.handle, C.byref(cam), C.byref(integ), spp, shard_index, shard_count, n_threads, max_waves,
+                                 film.ctypes.data_as(C.POINTER(C.c_double)), C.byref(scale), st)
+        if rc != 0:
+            raise RuntimeError("orc_render failed")
+        keys = ["samples", "extend_rays", "shadow_rays", "segments", "nodes", "tris", "stree_nodes", "dtree_nodes"]
+        return film, scale.value, dict(zip(keys, list(st)))
+
+
+def rel_mse(img, ref):
+    """mean((I-R)^2 / (R^2 + 1e-2)) on linear RGB."""
+    img = np.asarray(img, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    return float(np.mean((img - ref) ** 2 / (ref ** 2 + 1e-2)))
