@@ -1,0 +1,161 @@
+"""GPU parity tests (need an MI355X): the HIP path through the C ABI (libptgpu.so) against the CPU oracle on the
+same seeded inputs. Integer / index / hit-record work is compared bit for bit; images statistically (relMSE),
+because device libm (sin, cos, log1p, cosh, atan2) differs from glibc in the last ulp and a single flipped
+discrete decision re-routes a path."""
+import numpy as np
+import pytest
+
+import oracle_bind as ob
+import path_tracer_amd as pt
+import scenes_util as su
+
+pytestmark = pytest.mark.gpu
+
+
+def assert_hits_bit_exact(gpu, cpu):
+    assert (gpu["hit"] == cpu["hit"]).all()
+    for k in ("mesh_index", "triangle_index", "leaf_index"):
+        assert (gpu[k] == cpu[k]).all(), k
+    for k in ("t", "b0", "b1", "b2"):
+        assert (gpu[k].view(np.uint32) == cpu[k].view(np.uint32)).all(), k
+
+
+def both(scene, ctx):
+    ctx.set_scene(scene)
+    return ob.OracleScene(scene)
+
+
+# ------------------------------------------------------------------ BVH layout + hits, bit exact
+@pytest.mark.parametrize("n_tris,seed", [(1, 0), (2, 1), (37, 2), (500, 3), (5000, 4)])
+def test_bvh_layout_and_hits_random_soup(gpu_ctx, n_tris, seed):
+    rng = np.random.default_rng(seed)
+    sc = su.random_soup(rng, n_tris, n_meshes=min(3, n_tris))
+    o = both(sc, gpu_ctx)
+    gn, gl = gpu_ctx.scene_bvh()
+    on, ol = o.bvh()
+    assert gn.shape == on.shape and (gn == on).all()      # nodes word for word
+    assert (gl == ol).all()                                # leaf order
+    info = o.info()
+    assert gpu_ctx.scene_info()["n_emissive_tris"] == info["n_emissive_tris"]
+    for finite in (False, True):
+        rays = su.random_rays(rng, 20000, info["bounds"][:3] - 0.5, info["bounds"][3:] + 0.5, finite_tmax=finite)
+        assert_hits_bit_exact(gpu_ctx.trace(rays), o.trace(rays))
+
+
+def test_hits_on_coplanar_duplicates_and_shared_edges(gpu_ctx):
+    """Equal-t ties (duplicate meshes), rays through shared vertices/edges (f64 fallback), zero-extent boxes."""
+    sc = su.grid_scene(8)
+    o = both(sc, gpu_ctx)
+    rays = su.grid_rays(8)
+    g, c = gpu_ctx.trace(rays), o.trace(rays)
+    assert c["hit"].sum() > 0.5 * len(rays)
+    assert_hits_bit_exact(g, c)
+
+
+def test_empty_batch_and_misses(gpu_ctx):
+    sc = su.grid_scene(2)
+    both(sc, gpu_ctx)
+    assert len(gpu_ctx.trace(np.zeros((0, 7), dtype=np.float32))) == 0
+    rays = np.array([[0.5, 0.5, 5, 0, 0, 1, np.inf], [50, 50, 5, 0, 0, -1, np.inf], [0.5, 0.5, 5, 0, 0, -1, 1.0]], dtype=np.float32)
+    h = gpu_ctx.trace(rays)
+    assert (h["hit"] == 0).all() and (h["t"] == 0).all()
+
+
+@pytest.mark.parametrize("name", ["cornell-box", "veach-bidir", "veach-mis"])
+def test_hits_on_shipped_scenes(gpu_ctx, name):
+    sc = pt.LoadedScene(name)
+    o = both(sc, gpu_ctx)
+    gn, gl = gpu_ctx.scene_bvh()
+    on, ol = o.bvh()
+    assert (gn == on).all() and (gl == ol).all()
+    info = o.info()
+    rng = np.random.default_rng(7)
+    rays = su.random_rays(rng, 200000, info["bounds"][:3], info["bounds"][3:])
+    g, c = gpu_ctx.trace(rays), o.trace(rays)
+    assert c["hit"].mean() > 0.3
+    assert_hits_bit_exact(g, c)
+    # Scene::occluded between hit points (unnormalised segment, t_max 0.9999)
+    idx = np.nonzero(c["hit"])[0][:50000]
+    p = rays[idx, :3] + rays[idx, 3:6] * c["t"][idx, None]
+    a, b = p[:-1], p[1:]
+    assert (gpu_ctx.occluded(a, b) == o.occluded(a, b)).all()
+
+
+# ------------------------------------------------------------------ furnace (README.md:6): RGB [1,1,1]
+@pytest.mark.parametrize("kind,integrator,mode", [
+    ("plain", pt.INTEGRATOR_PATH, pt.MODE_PT), ("plain", pt.INTEGRATOR_PATH, pt.MODE_NEE), ("plain", pt.INTEGRATOR_PATH, pt.MODE_MIS),
+    ("glass", pt.INTEGRATOR_PATH, pt.MODE_MIS), ("skip", pt.INTEGRATOR_PATH, pt.MODE_MIS), ("plain", pt.INTEGRATOR_LIGHTPATH, pt.MODE_MIS),
+    ("glass", pt.INTEGRATOR_LIGHTPATH, pt.MODE_MIS),
+])
+def test_gpu_furnace_is_white(gpu_ctx, kind, integrator, mode):
+    sc = su.furnace_scene(kind)
+    gpu_ctx.set_scene(sc)
+    light = integrator == pt.INTEGRATOR_LIGHTPATH
+    gpu_ctx.set_camera(pt.make_camera(su.IDENTITY, 79.5 if light else 19.5, 16, 16))
+    spp = 65536 if light else 4096  # the GPU can afford far more samples than scenes-test's 64
+    film, scale, st = gpu_ctx.render(pt.make_integrator(integrator, 16, mode), spp)
+    mean = (film * scale).mean(axis=(0, 1))
+    assert st["samples"] == 16 * 16 * spp
+    assert np.abs(mean - 1.0).max() < 1e-3 + (4e-3 if light else 0.0), mean   # north_star: within 1e-3
+
+
+# ------------------------------------------------------------------ images vs the oracle
+def _compare(gpu_ctx, name, integrator_kind, res, spp_gpu, spp_cpu, tol, **ov):
+    sc = pt.LoadedScene(name, resx=res[0], resy=res[1], **ov)
+    o = ob.OracleScene(sc)
+    gpu_ctx.load(sc)
+    integ = pt.IntegratorDesc.from_buffer_copy(sc.integrator)
+    integ.kind = integrator_kind
+    gf, gs, gst = gpu_ctx.render(integ, spp_gpu)
+    cf, cs, cst = o.render(sc.camera, integ, spp_cpu)
+    g, c = gf * gs, cf * cs
+    # compare at reduced resolution: both images are Monte Carlo estimates, so residual noise is averaged down
+    k = 8
+    gb = g.reshape(res[1] // k, k, res[0] // k, k, 3).mean(axis=(1, 3))
+    cb = c.reshape(res[1] // k, k, res[0] // k, k, 3).mean(axis=(1, 3))
+    err = ob.rel_mse(gb, cb)
+    assert abs(g.mean() / c.mean() - 1.0) < 0.02, (g.mean(), c.mean())
+    assert err < tol, err
+    return gst, cst
+
+
+def test_cornell_path_image_matches_oracle(gpu_ctx):
+    gst, cst = _compare(gpu_ctx, "cornell-box", pt.INTEGRATOR_PATH, (128, 128), 1024, 256, 2e-3, max_depth=8)
+    # same number of rays per sample within noise: the two walk the same path distribution
+    assert abs(gst["extend_rays"] / gst["samples"] - cst["extend_rays"] / cst["samples"]) < 0.02
+    assert abs(gst["shadow_rays"] / gst["samples"] - cst["shadow_rays"] / cst["samples"]) < 0.02
+
+
+def test_veach_mis_path_image_matches_oracle(gpu_ctx):
+    _compare(gpu_ctx, "veach-mis", pt.INTEGRATOR_PATH, (160, 96), 1024, 128, 2e-3)
+
+
+def test_cornell_lightpath_image_matches_oracle(gpu_ctx):
+    _compare(gpu_ctx, "cornell-box", pt.INTEGRATOR_LIGHTPATH, (128, 128), 1024, 256, 2e-2, max_depth=8)
+
+
+def test_shards_sum_to_the_whole(gpu_ctx):
+    """ptgpu_render_shard: sample indices i % n == k. Every (pixel, sample) has its own RNG stream, so the shards'
+    films add up to the single-GPU film up to f64 atomic-add order."""
+    sc = pt.LoadedScene("cornell-box", resx=64, resy=64, max_depth=6)
+    gpu_ctx.load(sc)
+    whole, s, _ = gpu_ctx.render(sc.integrator, 24)
+    parts = sum(gpu_ctx.render(sc.integrator, 24, k, 3)[0] for k in range(3))
+    assert np.allclose(parts, whole, rtol=1e-9, atol=1e-12)
+
+
+def test_small_batches_equal_one_big_batch(gpu_ctx):
+    sc = pt.LoadedScene("cornell-box", resx=64, resy=64, max_depth=6)
+    gpu_ctx.load(sc)
+    a, _, _ = gpu_ctx.render(sc.integrator, 16)
+    gpu_ctx.set_batch_paths(64 * 64 * 3)
+    b, _, _ = gpu_ctx.render(sc.integrator, 16)
+    gpu_ctx.set_batch_paths(0)
+    assert np.allclose(a, b, rtol=1e-9, atol=1e-12)
+
+
+def test_error_paths(gpu_ctx):
+    with pytest.raises(pt.PtError):
+        gpu_ctx.render(pt.make_integrator(7, 4, 0), 1)
+    with pytest.raises(pt.PtError):
+        gpu_ctx.render(pt.make_integrator(pt.INTEGRATOR_PATH, 4, pt.MODE_MIS), 4, shard_index=3, shard_count=2)
