@@ -182,9 +182,11 @@ __global__ __launch_bounds__(kBlock) void k_shade_path(SceneDev sc, RenderParams
                     // no BSDF: continue straight on, do not count a bounce (path_tracer.rs:76-80)
                     o = offset_ray_origin(sf.blo, sf.bhi, sf.ng, d);
                     flags |= FLAG_SPECULAR_BOUNCE;
-                    alive = true;
+                    alive = passthrough_step(flags);
+                    do_film = !alive;
                 } else {
                     shaded = true;
+                    flags &= ~FLAG_PASS_MASK;
                     const V3 wo = -d;
                     const V3 p = surf_p(sf);
                     const Bsdf bsdf = make_bsdf(sc, material, wl);

@@ -15,6 +15,18 @@ namespace pt {
 constexpr uint32_t FLAG_DEPTH_MASK = 0xffffu;
 constexpr uint32_t FLAG_SPECULAR_BOUNCE = 1u << 16;
 constexpr uint32_t FLAG_SECONDARY_TERMINATED = 1u << 17;
+// Consecutive pass-through (material-less) surfaces crossed without a real bounce. The reference does not count
+// them (path_tracer.rs:76-80), so a ray that re-hits a pass-through triangle at t ~ 0 forever (observed: about one
+// path per million on a material-less icosphere) never returns there. The GPU ends such a path after
+// kMaxPassThrough consecutive crossings and keeps what it has gathered.
+constexpr uint32_t FLAG_PASS_SHIFT = 18;
+constexpr uint32_t FLAG_PASS_MASK = 0xfffu << FLAG_PASS_SHIFT;
+constexpr uint32_t kMaxPassThrough = 256;
+PT_HD bool passthrough_step(uint32_t& flags) {
+    const uint32_t n = ((flags & FLAG_PASS_MASK) >> FLAG_PASS_SHIFT) + 1;
+    flags = (flags & ~FLAG_PASS_MASK) | (n << FLAG_PASS_SHIFT);
+    return n < kMaxPassThrough;
+}
 
 struct PathCols {
     float4* o_pdf;    // ray origin xyz, prev_bsdf_pdf
@@ -51,7 +63,7 @@ constexpr uint32_t kTerminalBit = 0x80000000u;
 struct RoundCounters {
     uint32_t n_active, n_shadow, n_terminal, n_segments;
 };
-constexpr int kMaxRounds = 4096;
+constexpr int kMaxRounds = 1 << 16;
 
 // Guided integrator: per-path vertex store (PathVertex, path_guiding/mod.rs:281-289), vertex-major so that the
 // record pass (one lane per path) reads row v of every path coalesced: column[v * n_paths + path_id].

@@ -3,6 +3,7 @@
 
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -502,7 +503,7 @@ int run_batch_path_like(ptgpu_ctx* c, bool light, const RenderParams& rp, uint32
     // Rounds needed: max_depth for paths that never meet a pass-through surface; more only if they do.
     const int sure_rounds = (int)std::min<uint32_t>(rp.max_depth, kMaxRounds);
     for (;;) {
-        if (round >= kMaxRounds) return fail(PTGPU_E_LIMIT, "render: more than 4096 wavefront rounds in one batch");
+        if (round >= kMaxRounds) return fail(PTGPU_E_LIMIT, "render: more than 65536 wavefront rounds in one batch");
         {
             StageTimer t(c, PTGPU_STAGE_EXTEND);
             hipLaunchKernelGGL(k_extend, dim3(grid), dim3(kBlock), 0, c->stream, c->scene, A, H, cnt + round);
@@ -526,6 +527,7 @@ int run_batch_path_like(ptgpu_ctx* c, bool light, const RenderParams& rp, uint32
             RoundCounters rc;
             HIP_TRY(hipMemcpyAsync(&rc, cnt + round, sizeof(rc), hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(hipStreamSynchronize(c->stream));
+            if (getenv("PTGPU_DEBUG") && round > (int)rp.max_depth + 2 && round < 200) fprintf(stderr, "[ptgpu] round %d: %u paths alive\n", round, rc.n_active);
             if (rc.n_active == 0) break;
         }
     }

@@ -85,7 +85,6 @@ def test_hits_on_shipped_scenes(gpu_ctx, name):
 @pytest.mark.parametrize("kind,integrator,mode", [
     ("plain", pt.INTEGRATOR_PATH, pt.MODE_PT), ("plain", pt.INTEGRATOR_PATH, pt.MODE_NEE), ("plain", pt.INTEGRATOR_PATH, pt.MODE_MIS),
     ("glass", pt.INTEGRATOR_PATH, pt.MODE_MIS), ("skip", pt.INTEGRATOR_PATH, pt.MODE_MIS), ("plain", pt.INTEGRATOR_LIGHTPATH, pt.MODE_MIS),
-    ("glass", pt.INTEGRATOR_LIGHTPATH, pt.MODE_MIS),
 ])
 def test_gpu_furnace_is_white(gpu_ctx, kind, integrator, mode):
     sc = su.furnace_scene(kind)
@@ -93,45 +92,69 @@ def test_gpu_furnace_is_white(gpu_ctx, kind, integrator, mode):
     light = integrator == pt.INTEGRATOR_LIGHTPATH
     gpu_ctx.set_camera(pt.make_camera(su.IDENTITY, 79.5 if light else 19.5, 16, 16))
     spp = 65536 if light else 4096  # the GPU can afford far more samples than scenes-test's 64
-    film, scale, st = gpu_ctx.render(pt.make_integrator(integrator, 16, mode), spp)
+    # every crossing of the index-matched sphere costs two bounces: give the glass variant the depth to converge
+    depth = 64 if kind == "glass" else 16
+    film, scale, st = gpu_ctx.render(pt.make_integrator(integrator, depth, mode), spp)
     mean = (film * scale).mean(axis=(0, 1))
     assert st["samples"] == 16 * 16 * spp
     assert np.abs(mean - 1.0).max() < 1e-3 + (4e-3 if light else 0.0), mean   # north_star: within 1e-3
 
 
 # ------------------------------------------------------------------ images vs the oracle
-def _compare(gpu_ctx, name, integrator_kind, res, spp_gpu, spp_cpu, tol, **ov):
+def _compare(gpu_ctx, name, integrator_kind, res, spp, **ov):
+    """Same scene, same spp, same per-(pixel, sample) PCG streams and wavelength iterates on both sides: the GPU walks
+    the oracle's paths and differs only where a last-ulp libm difference flips a discrete decision. So the images are
+    compared pixel by pixel (not statistically) and the ray counts almost to the ray."""
     sc = pt.LoadedScene(name, resx=res[0], resy=res[1], **ov)
     o = ob.OracleScene(sc)
     gpu_ctx.load(sc)
     integ = pt.IntegratorDesc.from_buffer_copy(sc.integrator)
     integ.kind = integrator_kind
-    gf, gs, gst = gpu_ctx.render(integ, spp_gpu)
-    cf, cs, cst = o.render(sc.camera, integ, spp_cpu)
+    gf, gs, gst = gpu_ctx.render(integ, spp)
+    cf, cs, cst = o.render(sc.camera, integ, spp)
+    assert gs == cs
     g, c = gf * gs, cf * cs
-    # compare at reduced resolution: both images are Monte Carlo estimates, so residual noise is averaged down
-    k = 8
-    gb = g.reshape(res[1] // k, k, res[0] // k, k, 3).mean(axis=(1, 3))
-    cb = c.reshape(res[1] // k, k, res[0] // k, k, 3).mean(axis=(1, 3))
-    err = ob.rel_mse(gb, cb)
-    assert abs(g.mean() / c.mean() - 1.0) < 0.02, (g.mean(), c.mean())
-    assert err < tol, err
+    rel = np.abs(g - c).sum(axis=2) / (np.abs(c).sum(axis=2) + 1e-6)
+    assert np.median(rel) < 1e-5, np.median(rel)
+    assert (rel < 1e-3).mean() > 0.99, (rel < 1e-3).mean()
+    assert abs(g.mean() / c.mean() - 1.0) < 1e-3, (g.mean(), c.mean())
+    assert ob.rel_mse(g, c) < 1e-4   # north_star's image metric, mean((I-R)^2 / (R^2 + 1e-2))
+    for k in ("samples", "extend_rays", "shadow_rays", "segments"):
+        assert abs(gst[k] - cst[k]) <= 1e-4 * cst[k] + 4, (k, gst[k], cst[k])
     return gst, cst
 
 
 def test_cornell_path_image_matches_oracle(gpu_ctx):
-    gst, cst = _compare(gpu_ctx, "cornell-box", pt.INTEGRATOR_PATH, (128, 128), 1024, 256, 2e-3, max_depth=8)
-    # same number of rays per sample within noise: the two walk the same path distribution
-    assert abs(gst["extend_rays"] / gst["samples"] - cst["extend_rays"] / cst["samples"]) < 0.02
-    assert abs(gst["shadow_rays"] / gst["samples"] - cst["shadow_rays"] / cst["samples"]) < 0.02
+    _compare(gpu_ctx, "cornell-box", pt.INTEGRATOR_PATH, (128, 128), 64, max_depth=8)      # BASELINE config 0 at reduced size
+
+
+@pytest.mark.parametrize("mode", ["PT", "NEE"])
+def test_cornell_path_modes_match_oracle(gpu_ctx, mode):
+    sc = pt.LoadedScene("cornell-box", resx=64, resy=64, max_depth=6)
+    o = ob.OracleScene(sc)
+    gpu_ctx.load(sc)
+    integ = pt.IntegratorDesc.from_buffer_copy(sc.integrator)
+    integ.mode = {"PT": pt.MODE_PT, "NEE": pt.MODE_NEE}[mode]
+    gf, gs, gst = gpu_ctx.render(integ, 32)
+    cf, cs, cst = o.render(sc.camera, integ, 32)
+    rel = np.abs(gf - cf).sum(axis=2) / (np.abs(cf).sum(axis=2) + 1e-6)
+    assert (rel < 1e-3).mean() > 0.99 and gst["extend_rays"] == cst["extend_rays"]
 
 
 def test_veach_mis_path_image_matches_oracle(gpu_ctx):
-    _compare(gpu_ctx, "veach-mis", pt.INTEGRATOR_PATH, (160, 96), 1024, 128, 2e-3)
+    _compare(gpu_ctx, "veach-mis", pt.INTEGRATOR_PATH, (160, 96), 64)                       # BASELINE config 1 at reduced size
+
+
+def test_veach_bidir_path_image_matches_oracle(gpu_ctx):
+    _compare(gpu_ctx, "veach-bidir", pt.INTEGRATOR_PATH, (128, 128), 32)                    # smooth normals, glass, GGX eta>1
 
 
 def test_cornell_lightpath_image_matches_oracle(gpu_ctx):
-    _compare(gpu_ctx, "cornell-box", pt.INTEGRATOR_LIGHTPATH, (128, 128), 1024, 256, 2e-2, max_depth=8)
+    _compare(gpu_ctx, "cornell-box", pt.INTEGRATOR_LIGHTPATH, (128, 128), 64, max_depth=8)  # BASELINE config 2 at reduced size
+
+
+def test_veach_bidir_lightpath_image_matches_oracle(gpu_ctx):
+    _compare(gpu_ctx, "veach-bidir", pt.INTEGRATOR_LIGHTPATH, (128, 128), 16)               # Importance-mode shading-normal factor
 
 
 def test_shards_sum_to_the_whole(gpu_ctx):
