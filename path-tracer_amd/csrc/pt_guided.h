@@ -1,7 +1,489 @@
-// pt_guided.h — guided integrator state (SD-tree on device + host refinement). Filled in below.
+// pt_guided.h — device side of the `guided` integrator (Müller et al. practical path guiding as the reference
+// implements it): SD-tree lookups, guided direction sampling, the per-path vertex store and the back-to-front
+// record pass. Restates pt/src/integrator/path_guiding/{mod,stree,dtree}.rs; quirks kept on purpose are marked.
 #pragma once
-#include "pt_types.h"
+#include "pt_kernels.h"
+
 namespace pt {
-struct GuidedState;
+
+struct GuidedState;  // host-side (ptgpu_guided_api.inc)
 void guided_free(GuidedState* g);
+
+// Flat SD-tree in HBM (built by HostSdTree::flatten).
+//   snodes[i]    = {left, right, split_axis, leaf_id}; left == 0 <=> leaf
+//   leaf_info[l] = {first node of the leaf's SAMPLING quadtree in s_*, first node of its COLLECTOR quadtree in c_*,
+//                   sampler mean == 0, -}
+//   quadtree node k of a tree at offset o: rad[o+k] = the 4 child sums, child[o+k] = 4 x u16 links (0 = leaf child);
+//   child numbering bit0 = x >= mid, bit1 = y >= mid (dtree.rs:331-352).
+// The collector sums c_rad and the per-leaf weights c_weight share ONE float buffer (c_rad first), which is what
+// ptgpu_guided_stats hands to the multi-GPU driver for its all-reduce.
+struct SdTreeDev {
+    const uint4* snodes;
+    const uint4* leaf_info;
+    const float4* s_rad;
+    const uint2* s_child;
+    float4* c_rad;
+    const uint2* c_child;
+    float* c_weight;
+    V3 blo, bhi;
+    uint32_t iteration;  // Guider::iteration: 0 = no guiding yet
+};
+
+PT_HD uint32_t child_link(uint2 packed, int c) { return (c < 2 ? packed.x >> (16 * c) : packed.y >> (16 * (c - 2))) & 0xffffu; }
+PT_HD float comp4(float4 v, int c) { return c == 0 ? v.x : (c == 1 ? v.y : (c == 2 ? v.z : v.w)); }
+
+PT_D V3 square_to_dir(V2 p) {  // path_guiding/mod.rs:404-410 (cylindrical, area preserving; z = world z)
+    float ct = 2.0f * p.x - 1.0f;
+    float phi = kTwoPi * p.y;
+    float st = safe_sqrtf(1.0f - ct * ct);
+    float s, c;
+    sincosf(phi, &s, &c);
+    return mk3(st * c, st * s, ct);
+}
+PT_D V2 dir_to_square(V3 d) {  // path_guiding/mod.rs:412-421
+    float ct = clampf(d.z, -1.0f, 1.0f);
+    float phi = atan2f(d.y, d.x);
+    while (phi < 0.0f) phi += kTwoPi;
+    return clamp2(V2{(ct + 1.0f) / 2.0f, phi * kInvTwoPi}, V2{0.0f, 0.0f}, V2{1.0f, 1.0f});
+}
+
+// STree::leaf (stree.rs:202-229): halve along the node's axis until a leaf; also returns the leaf's box.
+PT_D uint32_t stree_leaf(const SdTreeDev& t, V3 p, V3& lo, V3& hi) {
+    lo = t.blo;
+    hi = t.bhi;
+    uint32_t ni = 0;
+    for (int guard = 0; guard < 128; guard++) {
+        const uint4 n = t.snodes[ni];
+        if (n.x == 0) return n.w;
+        const int ax = (int)n.z;
+        const float mid = (get(lo, ax) + get(hi, ax)) / 2.0f;
+        if (get(p, ax) < mid) {
+            set(hi, ax, mid);
+            ni = n.x;
+        } else {
+            set(lo, ax, mid);
+            ni = n.y;
+        }
+    }
+    return t.snodes[ni].w;
+}
+
+// Quadtree cells are dyadic: cell (ix, iy) at `level` spans [ix, ix+1] * 2^-level. The reference halves boxes with
+// (min+max)/2, which is exact for these values, so integer cell coordinates reproduce its boxes bit for bit.
+struct Cell {
+    uint32_t ix, iy, level;
+};
+PT_HD Box2 cell_box(Cell c) {
+    const float s = u2f((127u - c.level) << 23);  // 2^-level
+    return Box2{{(float)c.ix * s, (float)c.iy * s}, {(float)(c.ix + 1) * s, (float)(c.iy + 1) * s}};
+}
+PT_HD int cell_child_of(Cell c, V2 p, Cell& out) {  // child_index (dtree.rs:331-352)
+    const Box2 b = cell_box(c);
+    const V2 mid = box2_centroid(b);
+    int r = 0;
+    if (!(p.x < mid.x)) r |= 1;
+    if (!(p.y < mid.y)) r |= 2;
+    out = Cell{2 * c.ix + (uint32_t)(r & 1), 2 * c.iy + (uint32_t)(r >> 1), c.level + 1};
+    return r;
+}
+constexpr uint32_t kMaxQuadLevel = 24;
+
+// DTree::sample (dtree.rs:98-153): one float per level, two at the leaf.
+PT_D V2 dtree_sample(const SdTreeDev& t, uint4 leaf, Rng& rng) {
+    if (leaf.z) {
+        const float a = rng_f32(rng), b = rng_f32(rng);
+        return V2{a, b};
+    }
+    uint32_t ni = 0;
+    Cell cell{0, 0, 0};
+    for (;;) {
+        const float4 r = t.s_rad[leaf.x + ni];
+        const int c = sample_discrete4(rng_f32(rng), r.x, r.y, r.z, r.w);
+        const Cell child{2 * cell.ix + (uint32_t)(c & 1), 2 * cell.iy + (uint32_t)(c >> 1), cell.level + 1};
+        const uint32_t link = child_link(t.s_child[leaf.x + ni], c);
+        if (link == 0 || child.level >= kMaxQuadLevel) {
+            const float a = rng_f32(rng), b = rng_f32(rng);
+            const Box2 cb = cell_box(child);
+            V2 s = cb.lo + V2{a, b} * box2_extent(cb);
+            s = min2(s, cb.hi - V2{kEps, kEps});
+            return clamp2(s, V2{0.0f, 0.0f}, V2{1.0f, 1.0f});
+        }
+        ni = link;
+        cell = child;
+    }
+}
+// DTree::pdf (dtree.rs:155-179): prod over levels of 4 * child / sum, times 1 / 4 pi.
+PT_D float dtree_pdf(const SdTreeDev& t, uint4 leaf, V2 p) {
+    if (leaf.z) return kInvFourPi;
+    float scales[kMaxQuadLevel + 1];
+    int n = 0;
+    uint32_t ni = 0;
+    Cell cell{0, 0, 0};
+    float result;
+    for (;;) {
+        const float4 r = t.s_rad[leaf.x + ni];
+        Cell child;
+        const int c = cell_child_of(cell, p, child);
+        const float rc = comp4(r, c);
+        if (rc == 0.0f) {
+            result = 0.0f;
+            break;
+        }
+        const float scale = 4.0f * rc / ((((0.0f + r.x) + r.y) + r.z) + r.w);
+        const uint32_t link = child_link(t.s_child[leaf.x + ni], c);
+        if (link == 0 || child.level >= kMaxQuadLevel) {
+            result = scale;
+            break;
+        }
+        scales[n++] = scale;
+        ni = link;
+        cell = child;
+    }
+    for (int i = n - 1; i >= 0; i--) result = scales[i] * result;  // innermost first, as the recursion multiplies
+    return result * kInvFourPi;
+}
+
+// Guider::sample (path_guiding/mod.rs:315-368).
+PT_D bool guider_sample(const SdTreeDev& t, const Bsdf& bsdf, const Frame& fr, V3 ng, V3 p, V3 wo, Rng& rng, BsdfSample& s) {
+    if (t.iteration == 0 || bsdf_is_specular(bsdf)) {
+        const float u1d = rng_f32(rng), ua = rng_f32(rng), ub = rng_f32(rng);
+        return bsdf_sample(bsdf, fr, ng, wo, u1d, ua, ub, true, s);
+    }
+    V3 lo, hi;
+    const uint4 leaf = t.leaf_info[stree_leaf(t, p, lo, hi)];
+    if (rng_f32(rng) < 0.5f) {
+        const V2 sq = dtree_sample(t, leaf, rng);
+        const V3 wi = square_to_dir(sq);
+        const float bp = bsdf_pdf(bsdf, fr, wo, wi) * 0.5f;
+        if (bp == 0.0f) return false;  // the tree proposed a direction the BSDF cannot produce: the walk ends here
+        s.pdf = bp + dtree_pdf(t, leaf, sq) * 0.5f;
+        s.f = bsdf_eval(bsdf, fr, ng, wo, wi, true);
+        s.wi = wi;
+        s.specular = false;
+        s.terminate_secondary = false;
+        return true;
+    }
+    const float u1d = rng_f32(rng), ua = rng_f32(rng), ub = rng_f32(rng);
+    if (!bsdf_sample(bsdf, fr, ng, wo, u1d, ua, ub, true, s)) return false;
+    s.pdf = 0.5f * s.pdf + 0.5f * dtree_pdf(t, leaf, dir_to_square(s.wi));
+    return true;
+}
+
+// DTree::record with the box filter (dtree.rs:200-207,235-289): weight += 1; splat `radiance` over every collector
+// leaf cell the footprint (a box of the size of the cell containing p, centred on p, clipped to the unit square)
+// overlaps, in proportion to the overlap. f32 atomics straight into HBM.
+PT_D void dtree_record_box(const SdTreeDev& t, uint32_t leaf_id, uint4 leaf, V2 p, float radiance) {
+    unsafeAtomicAdd(t.c_weight + leaf_id, 1.0f);
+    // DTree::leaf (dtree.rs:81-94): the cell that holds p
+    Cell cell{0, 0, 0};
+    {
+        uint32_t ni = 0;
+        for (;;) {
+            Cell child;
+            const int c = cell_child_of(cell, p, child);
+            const uint32_t link = child_link(t.c_child[leaf.y + ni], c);
+            cell = child;
+            if (link == 0 || child.level >= kMaxQuadLevel) break;
+            ni = link;
+        }
+    }
+    const Box2 lb = cell_box(cell);
+    Box2 fp = box2_around(p, box2_extent(lb));
+    fp = Box2{clamp2(V2{0.0f, 0.0f}, fp.lo, fp.hi), clamp2(V2{1.0f, 1.0f}, fp.lo, fp.hi)};  // Bounds2::clamp (bounds.rs:46-50)
+    const float fp_area = box2_area(fp);
+    // depth-first over (node, cell) pairs; children visited in index order like the recursion
+    struct Item {
+        uint32_t node;
+        Cell cell;
+    };
+    Item stack[3 * kMaxQuadLevel + 4];
+    int sp = 0;
+    stack[sp++] = Item{0, Cell{0, 0, 0}};
+    while (sp > 0) {
+        const Item it = stack[--sp];
+        const uint2 links = t.c_child[leaf.y + it.node];
+        float* rad = reinterpret_cast<float*>(t.c_rad + leaf.y + it.node);
+        for (int c = 3; c >= 0; c--) {  // pushed in reverse so that child 0 is expanded first
+            const Cell child{2 * it.cell.ix + (uint32_t)(c & 1), 2 * it.cell.iy + (uint32_t)(c >> 1), it.cell.level + 1};
+            const float w = box2_overlap(fp, cell_box(child)) / fp_area;
+            if (w == 0.0f || !(w == w)) continue;
+            const uint32_t link = child_link(links, c);
+            if (link == 0 || child.level >= kMaxQuadLevel) unsafeAtomicAdd(rad + c, radiance * w);
+            else if (sp < (int)(sizeof(stack) / sizeof(stack[0]))) stack[sp++] = Item{link, child};
+        }
+    }
+}
+
+// STree::record with the stochastic spatial filter (stree.rs:102-116,186-201).
+PT_D void stree_record(const SdTreeDev& t, V3 p, V3 wi, float radiance, Rng& rng) {
+    if (!isfinite(radiance) || radiance == 0.0f) return;
+    const V2 p2 = dir_to_square(wi);
+    V3 lo, hi;
+    (void)stree_leaf(t, p, lo, hi);
+    const V3 ext = hi - lo;
+    const V3 jlo = p - ext / 2.0f;  // Bounds3::around(p, extent)
+    const V3 jhi = p + ext / 2.0f;
+    const float u0 = rng_f32(rng), u1 = rng_f32(rng), u2 = rng_f32(rng);
+    const V3 q = clamp3(jlo + mk3(u0, u1, u2) * (jhi - jlo), t.blo, t.bhi);
+    const uint32_t leaf_id = stree_leaf(t, q, lo, hi);
+    dtree_record_box(t, leaf_id, t.leaf_info[leaf_id], p2, radiance);
+}
+
+struct GuidedParams {
+    VertexCols vtx;
+    PathTail tail;
+    uint32_t n_rows;       // max_depth + 1 vertex rows
+    uint32_t row_stride;   // = capacity
+    uint32_t write_film;   // only the last wave reaches the image (film.clear() per wave, mod.rs:80)
+    uint32_t shard_index, shard_count;
+    uint32_t tiles_x;
+};
+
+PT_HD uint32_t tile_of_pixel(uint32_t pixel, uint32_t resx, uint32_t tiles_x) { return (pixel / resx / 16u) * tiles_x + (pixel % resx) / 16u; }
+// Index of the pixel inside its 16x16 film tile in TileIter order (camera.rs:285-299) — what the reference's
+// tile-sequential wavelength recurrence depends on.
+PT_HD uint32_t index_in_tile(uint32_t pixel, uint32_t resx) {
+    const uint32_t x = pixel % resx, y = pixel / resx;
+    const uint32_t tx0 = (x / 16u) * 16u;
+    const uint32_t tw = resx - tx0 < 16u ? resx - tx0 : 16u;
+    return (x - tx0) + (y % 16u) * tw;
+}
+
+// Per-pass head of PathGuidingIntegrator::render (mod.rs:90-96). Visits every (pass, pixel) pair of the batch and
+// keeps those of this shard: tile t of pass k belongs to shard (t + k) % shard_count, so waves of 1, 2, 4 passes
+// still spread over all GPUs.
+__global__ __launch_bounds__(kBlock) void k_raygen_guided(SceneDev sc, CameraDev cam, RenderParams rp, GuidedParams gp, PathCols st, RoundCounters* cnt,
+                                                          uint32_t n_pairs, uint32_t n_pixels, uint64_t first_pass) {
+    const uint32_t stride = gridDim.x * blockDim.x;
+    const uint32_t n_iter = (n_pairs + stride - 1) / stride;
+    for (uint32_t it = 0; it < n_iter; it++) {
+        const uint32_t g = it * stride + blockIdx.x * blockDim.x + threadIdx.x;
+        bool mine = false;
+        uint32_t pixel = 0;
+        uint64_t pass = 0;
+        if (g < n_pairs) {
+            pixel = g % n_pixels;
+            pass = first_pass + g / n_pixels;
+            mine = (tile_of_pixel(pixel, cam.resx, gp.tiles_x) + pass) % gp.shard_count == gp.shard_index;
+        }
+        const uint32_t slot = wave_alloc(&cnt[0].n_active, mine);
+        if (mine) {
+            const uint32_t ix = pixel % cam.resx, iy = pixel / cam.resx;
+            Rng rng = rng_init_pixel(ix, iy, pass);
+            const float u0 = rng_f32(rng), u1 = rng_f32(rng);
+            V3 o, d;
+            camera_sample_we(cam, ix, iy, u0, u1, o, d);
+            const uint32_t lam = index_in_tile(pixel, cam.resx) + (pass == 0 ? 0u : 256u);
+            st.o_pdf[slot] = make_float4(o.x, o.y, o.z, 0.0f);
+            st.d_flags[slot] = make_float4(d.x, d.y, d.z, u2f(0u));
+            st.beta0[slot] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+            st.beta1[slot] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+            st.rng_px[slot] = make_uint4((uint32_t)rng.state, (uint32_t)(rng.state >> 32), pixel, lam);  // w: lambda index | nverts << 16
+            st.prev_p[slot] = make_float4(0.0f, 0.0f, 0.0f, u2f(slot));                                  // w: path id (vertex-store column)
+        }
+    }
+}
+
+PT_D void store_vertex(const GuidedParams& gp, uint32_t row, uint32_t pid, V3 p, V3 wi, float pdf, const Spec& f, const Spec& e) {
+    const size_t k = (size_t)row * gp.row_stride + pid;
+    gp.vtx.p_pdf[k] = make_float4(p.x, p.y, p.z, pdf);
+    gp.vtx.wi[k] = make_float4(wi.x, wi.y, wi.z, 0.0f);
+    store_spec(gp.vtx.f0, gp.vtx.f1, k, f);
+    store_spec(gp.vtx.e0, gp.vtx.e1, k, e);
+    gp.vtx.li0[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    gp.vtx.li1[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+}
+
+// One iteration of PathGuidingIntegrator::random_walk's loop body (mod.rs:139-278).
+__global__ __launch_bounds__(kBlock) void k_shade_guided(SceneDev sc, SdTreeDev tree, RenderParams rp, GuidedParams gp, PathCols in, HitCols hit, PathCols out,
+                                                         ShadowCols sh, const RoundCounters* cur, RoundCounters* nxt) {
+    const uint32_t n = cur->n_active;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    const uint32_t n_iter = (n + stride - 1) / stride;
+    for (uint32_t it = 0; it < n_iter; it++) {
+        const uint32_t i = it * stride + blockIdx.x * blockDim.x + threadIdx.x;
+        const bool valid = i < n;
+        bool alive = false, want_shadow = false, shaded = false, skipped_shadow = false, ended = false;
+        V3 o = mk3(0, 0, 0), d = mk3(0, 0, 1), prev_p = mk3(0, 0, 0), sh_from = mk3(0, 0, 0), sh_to = mk3(0, 0, 0);
+        float prev_pdf = 0.0f;
+        uint32_t flags = 0, pid = 0, nverts = 0, shadow_row = 0;
+        Spec beta = spec_splat(0.0f), contrib = spec_splat(0.0f);
+        uint4 rp4 = make_uint4(0, 0, 0, 0);
+        if (valid) {
+            const float4 o4 = in.o_pdf[i], d4 = in.d_flags[i], pp = in.prev_p[i];
+            o = mk3(o4.x, o4.y, o4.z);
+            d = mk3(d4.x, d4.y, d4.z);
+            prev_pdf = o4.w;
+            flags = f2u(d4.w);
+            rp4 = in.rng_px[i];
+            prev_p = mk3(pp.x, pp.y, pp.z);
+            pid = f2u(pp.w);
+            nverts = rp4.w >> 16;
+            const uint32_t prim = hit.prim[i];
+            if (prim == kNoHit) {
+                // miss vertex (mod.rs:140-150): far point along the ray, nothing emitted without an envmap
+                if (nverts < gp.n_rows) {
+                    store_vertex(gp, nverts, pid, o + d * 10000.0f, d, 1.0f, spec_splat(1.0f), spec_splat(0.0f));
+                    nverts++;
+                }
+                ended = true;
+            } else {
+                const float4 tb = hit.tb[i];
+                beta = load_spec(in.beta0, in.beta1, i);
+                const Lambdas wl = sample_visible(rp.lambda_u[rp4.w & 0xffffu]);
+                const Surface sf = make_surface(sc, prim, tb.y, tb.z, tb.w);
+                const int material = sc.mesh_info[sf.tri.mesh].material;
+                uint32_t depth = flags & FLAG_DEPTH_MASK;
+                if (material < 0) {
+                    // pass-through: no bounce counted and, unlike `path`, specular_bounce is left alone (mod.rs:153-156)
+                    o = offset_ray_origin(sf.blo, sf.bhi, sf.ng, d);
+                    alive = passthrough_step(flags);
+                    ended = !alive;
+                } else {
+                    shaded = true;
+                    flags &= ~FLAG_PASS_MASK;
+                    const V3 wo = -d;
+                    const V3 p = surf_p(sf);
+                    const Bsdf bsdf = make_bsdf(sc, material, wl);
+                    const bool specular = bsdf_is_specular(bsdf);
+                    const bool spec_bounce = (flags & FLAG_SPECULAR_BOUNCE) != 0;
+                    Spec emitted = spec_splat(0.0f);
+                    if (sf.tri.mesh < sc.n_emissive_meshes) {
+                        const bool direct = (depth == 0) || spec_bounce;
+                        if (rp.mode == MODE_PT || direct) emitted = light_emitted(sc, sf.tri, sf.ng, p, o, wl);
+                        else if (rp.mode == MODE_MIS) {
+                            const float pb = prev_pdf;
+                            const float pl = light_pdf_li(sf.tri, sf.ng, prev_p, p);
+                            const float w = (pb * pb) / (pb * pb + pl * pl);
+                            emitted = w * light_emitted(sc, sf.tri, sf.ng, p, o, wl);
+                        }
+                    }
+                    Rng rng{(uint64_t)rp4.x | ((uint64_t)rp4.y << 32), rng_inc_for_pixel(rp4.z % rp.resx, rp4.z / rp.resx)};
+                    bool has_nee = false;
+                    if (rp.mode != MODE_PT && !specular) {
+                        const float u1d = rng_f32(rng), ua = rng_f32(rng), ub = rng_f32(rng);
+                        Tri lt;
+                        float pmf;
+                        LiSample ls;
+                        if (choose_light(sc, u1d, lt, pmf) && light_sample_li(lt, p, ua, ub, ls)) {
+                            Spec f = bsdf_eval(bsdf, sf.frame, sf.ng, wo, ls.wl, true) / (ls.pdf * pmf);
+                            if (!spec_is_black(f)) {
+                                const V3 lp = (ls.blo + ls.bhi) / 2.0f;
+                                const Spec le = spectrum_eval(sc.emissions[lt.mesh], wl, sc.d65);
+                                if (rp.mode == MODE_NEE) contrib = f * le;
+                                else {
+                                    const float pl = ls.pdf;
+                                    const float pb = bsdf_pdf(bsdf, sf.frame, wo, ls.wl);
+                                    const float w = (pl * pl) / (pl * pl + pb * pb);
+                                    contrib = w * f * le;
+                                }
+                                const V3 w = normalize(lp - p);
+                                sh_from = offset_ray_origin(sf.blo, sf.bhi, sf.ng, w);
+                                sh_to = lp;
+                                has_nee = true;
+                            }
+                        }
+                    }
+                    BsdfSample bs;
+                    const bool ok = guider_sample(tree, bsdf, sf.frame, sf.ng, p, wo, rng, bs);
+                    rp4.x = (uint32_t)rng.state;
+                    rp4.y = (uint32_t)(rng.state >> 32);
+                    if (!ok) {
+                        // QUIRK kept: the walk breaks before the vertex is pushed, so this surface's emitted light
+                        // and its direct-light sample are lost (mod.rs:245-266). The reference still traced the
+                        // shadow ray; here it is only counted.
+                        skipped_shadow = has_nee;
+                        ended = true;
+                    } else {
+                        flags = specular ? (flags | FLAG_SPECULAR_BOUNCE) : (flags & ~FLAG_SPECULAR_BOUNCE);
+                        Spec fw;
+#pragma unroll
+                        for (int k = 0; k < NSW; k++) fw.v[k] = bs.f.v[k] / bs.pdf;
+                        if (!specular && nverts < gp.n_rows) {
+                            store_vertex(gp, nverts, pid, p, bs.wi, bs.pdf, fw, emitted);
+                            shadow_row = nverts;
+                            want_shadow = has_nee;
+                            nverts++;
+                        } else
+                            skipped_shadow = has_nee;
+                        beta = beta * fw;
+                        if (spec_is_black(beta)) ended = true;
+                        else {
+                            if (bs.terminate_secondary) flags |= FLAG_SECONDARY_TERMINATED;
+                            o = offset_ray_origin(sf.blo, sf.bhi, sf.ng, bs.wi);
+                            d = bs.wi;
+                            prev_p = p;
+                            prev_pdf = bs.pdf;
+                            depth += 1;
+                            flags = (flags & ~FLAG_DEPTH_MASK) | (depth & FLAG_DEPTH_MASK);
+                            alive = depth < rp.max_depth;
+                            ended = !alive;
+                        }
+                    }
+                }
+            }
+            rp4.w = (rp4.w & 0xffffu) | (nverts << 16);
+        }
+        const uint32_t a_slot = wave_alloc(&nxt->n_active, alive);
+        const uint32_t s_slot = wave_alloc(&nxt->n_shadow, want_shadow);
+        wave_count(&nxt->n_segments, shaded);
+        wave_count(&nxt->n_terminal, skipped_shadow);
+        if (alive) {
+            out.o_pdf[a_slot] = make_float4(o.x, o.y, o.z, prev_pdf);
+            out.d_flags[a_slot] = make_float4(d.x, d.y, d.z, u2f(flags));
+            store_spec(out.beta0, out.beta1, a_slot, beta);
+            out.rng_px[a_slot] = rp4;
+            out.prev_p[a_slot] = make_float4(prev_p.x, prev_p.y, prev_p.z, u2f(pid));
+        }
+        if (valid && ended) {
+            gp.tail.rng_px[pid] = rp4;
+            gp.tail.nverts_flags[pid] = flags;
+        }
+        if (want_shadow) {
+            sh.q0[s_slot] = make_float4(sh_from.x, sh_from.y, sh_from.z, u2f(pid));
+            sh.q1[s_slot] = make_float4(sh_to.x, sh_to.y, sh_to.z, u2f(shadow_row));
+            store_spec(sh.q2, sh.q3, s_slot, contrib);
+        }
+    }
+}
+
+// NEE visibility for the guided walk: an unoccluded sample becomes the vertex's li_sample_contribution.
+__global__ __launch_bounds__(kBlock) void k_occlude_guided(SceneDev sc, GuidedParams gp, ShadowCols sh, const RoundCounters* cnt) {
+    const uint32_t n = cnt->n_shadow;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) {
+        const float4 a = sh.q0[j], b = sh.q1[j];
+        if (!scene_occluded(sc, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z))) {
+            const size_t k = (size_t)f2u(b.w) * gp.row_stride + f2u(a.w);
+            gp.vtx.li0[k] = sh.q2[j];
+            gp.vtx.li1[k] = sh.q3[j];
+        }
+    }
+}
+
+// Back-to-front pass over each finished path (mod.rs:106-116): what arrives at a vertex from further along the path
+// is recorded into the SD-tree, then folded through the vertex. One lane per path; row v of all paths is contiguous.
+__global__ __launch_bounds__(kBlock) void k_guide_record(SceneDev sc, SdTreeDev tree, RenderParams rp, GuidedParams gp, uint32_t n_paths) {
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t pid = blockIdx.x * blockDim.x + threadIdx.x; pid < n_paths; pid += stride) {
+        const uint4 rp4 = gp.tail.rng_px[pid];
+        const uint32_t flags = gp.tail.nverts_flags[pid];
+        const uint32_t nverts = rp4.w >> 16;
+        Rng rng{(uint64_t)rp4.x | ((uint64_t)rp4.y << 32), rng_inc_for_pixel(rp4.z % rp.resx, rp4.z / rp.resx)};
+        Spec l = spec_splat(0.0f);
+        for (uint32_t v = nverts; v-- > 0;) {
+            const size_t k = (size_t)v * gp.row_stride + pid;
+            const float4 pp = gp.vtx.p_pdf[k], wi = gp.vtx.wi[k];
+            stree_record(tree, mk3(pp.x, pp.y, pp.z), mk3(wi.x, wi.y, wi.z), spec_average(l) / pp.w, rng);
+            l = l * load_spec(gp.vtx.f0, gp.vtx.f1, k);
+            l = l + load_spec(gp.vtx.li0, gp.vtx.li1, k);
+            l = l + load_spec(gp.vtx.e0, gp.vtx.e1, k);
+        }
+        if (gp.write_film) {
+            const Lambdas wl = sample_visible(rp.lambda_u[rp4.w & 0xffffu]);
+            film_add(sc, rp.film, rp4.z, l, wl, (flags & FLAG_SECONDARY_TERMINATED) != 0);
+        }
+    }
+}
+
 }  // namespace pt

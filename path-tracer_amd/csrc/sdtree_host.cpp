@@ -1,1 +1,182 @@
-// sdtree_host.cpp — host-side SD-tree refinement (filled in with the guided integrator)
+// sdtree_host.cpp — see sdtree_host.h. Host code only.
+#include "sdtree_host.h"
+
+#include <utility>
+
+namespace pt {
+namespace {
+
+// DTree::build (dtree.rs:185-198): interior children take the sum of their subtree, bottom-up.
+float rebuild_sums(HostDTree& t, uint16_t ni) {
+    for (int c = 0; c < 4; c++) {
+        const uint16_t ch = t.nodes[ni].child[c];
+        if (ch != 0) t.nodes[ni].rad[c] = rebuild_sums(t, ch);
+    }
+    return t.nodes[ni].sum();
+}
+
+// NodeList::free_recursive (dtree.rs:399-410)
+void release_subtree(HostDTree& t, uint16_t ni) {
+    if (ni == 0) return;
+    t.free_slots.push_back(ni);
+    const HostDNode n = t.nodes[ni];
+    for (int c = 0; c < 4; c++)
+        if (n.child[c] != 0) release_subtree(t, n.child[c]);
+}
+
+// NodeList::add (dtree.rs:390-398); false when a 16-bit link cannot address the new node.
+bool add_node(HostDTree& t, const HostDNode& n, uint16_t* index) {
+    if (!t.free_slots.empty()) {
+        *index = t.free_slots.back();
+        t.free_slots.pop_back();
+        t.nodes[*index] = n;
+        return true;
+    }
+    if (t.nodes.size() >= 65535) return false;
+    *index = (uint16_t)t.nodes.size();
+    t.nodes.push_back(n);
+    return true;
+}
+
+// DTree::subdivide_and_clear (dtree.rs:291-324): drop subtrees carrying < threshold of the total, split leaves
+// carrying more, then zero every sum and the weight.
+bool refine_directional(HostDTree& t, float threshold) {
+    std::vector<std::pair<uint16_t, int>> todo;
+    todo.emplace_back((uint16_t)0, 1);
+    const float total = t.nodes[0].sum();
+    while (!todo.empty()) {
+        const auto [ni, depth] = todo.back();
+        todo.pop_back();
+        const HostDNode snapshot = t.nodes[ni];  // the reference works on a copy taken here
+        for (int c = 0; c < 4; c++) {
+            float frac;
+            if (total > 0.0f) frac = snapshot.rad[c] / total;
+            else {
+                frac = 1.0f;
+                for (int k = 0; k < depth; k++) frac *= 0.25f;  // 0.25f32.powi(depth), exact
+            }
+            if (frac < threshold) {
+                release_subtree(t, snapshot.child[c]);
+                t.nodes[ni].child[c] = 0;
+                continue;
+            }
+            if (snapshot.child[c] == 0) {
+                HostDNode fresh;
+                for (int k = 0; k < 4; k++) fresh.rad[k] = snapshot.rad[c] / 4.0f;
+                uint16_t idx;
+                if (!add_node(t, fresh, &idx)) return false;
+                t.nodes[ni].child[c] = idx;
+                todo.emplace_back(idx, depth + 1);
+            } else {
+                todo.emplace_back(snapshot.child[c], depth + 1);
+            }
+        }
+    }
+    t.weight = 0.0f;
+    for (HostDNode& n : t.nodes)
+        for (int k = 0; k < 4; k++) n.rad[k] = 0.0f;
+    return true;
+}
+
+inline uint2 pack_children(const HostDNode& n) {
+    return make_uint2((uint32_t)n.child[0] | ((uint32_t)n.child[1] << 16), (uint32_t)n.child[2] | ((uint32_t)n.child[3] << 16));
+}
+
+}  // namespace
+
+void HostSdTree::init(V3 lo, V3 hi) {
+    nodes.clear();
+    nodes.emplace_back();
+    nodes[0].sampler.reset_root();
+    nodes[0].collector.reset_root();
+    const Box3 scene{lo, hi};
+    bounds = box_around(box_centroid(scene), splat(max_comp(box_extent(scene))));
+}
+
+bool HostSdTree::new_iteration(float directional_threshold, float spatial_threshold, uint32_t iteration, std::string* err) {
+    // subdivide_nodes (stree.rs:55-101): threshold = base * sqrt(2^iteration); freshly appended children are
+    // visited by the same sweep and may split again.
+    float pow2 = 1.0f;
+    for (uint32_t k = 0; k < iteration; k++) pow2 *= 2.0f;
+    const float threshold = spatial_threshold * sqrtf(pow2);
+    for (size_t i = 0; i < nodes.size(); i++) {
+        if (nodes[i].left != 0 || !(nodes[i].collector.weight > threshold)) continue;
+        const uint32_t l = (uint32_t)nodes.size(), r = l + 1;
+        HostSNode a, b;
+        a.sampler = nodes[i].sampler;
+        a.collector = nodes[i].collector;
+        b.sampler = std::move(nodes[i].sampler);
+        b.collector = std::move(nodes[i].collector);
+        nodes[i].sampler = HostDTree{};
+        nodes[i].collector = HostDTree{};
+        a.axis = b.axis = (nodes[i].axis + 1) % 3;
+        a.depth = b.depth = nodes[i].depth + 1;
+        a.collector.weight /= 2.0f;
+        b.collector.weight /= 2.0f;
+        nodes[i].left = l;
+        nodes[i].right = r;
+        nodes.push_back(std::move(a));
+        nodes.push_back(std::move(b));
+    }
+    // STreeNode::subdivide_dtree for every leaf (stree.rs:49-53,255-260)
+    for (HostSNode& n : nodes) {
+        if (n.left != 0) continue;
+        rebuild_sums(n.collector, 0);
+        n.sampler.weight = n.collector.weight;  // emit_into (dtree.rs:325-328)
+        n.sampler.nodes = n.collector.nodes;
+        n.sampler.free_slots = n.collector.free_slots;
+        if (!refine_directional(n.collector, directional_threshold)) {
+            if (err) *err = "a directional quadtree needs more than 65535 nodes (u16 child links)";
+            return false;
+        }
+    }
+    return true;
+}
+
+void HostSdTree::flatten(SdTreeFlat& out) const {
+    out.snodes.assign(nodes.size(), make_uint4(0, 0, 0, 0));
+    out.leaf_info.clear();
+    out.s_rad.clear();
+    out.s_child.clear();
+    out.c_child.clear();
+    out.leaf_snode.clear();
+    for (size_t i = 0; i < nodes.size(); i++) {
+        const HostSNode& n = nodes[i];
+        if (n.left != 0) {
+            out.snodes[i] = make_uint4(n.left, n.right, n.axis, 0xffffffffu);
+            continue;
+        }
+        const uint32_t leaf = (uint32_t)out.leaf_info.size();
+        out.snodes[i] = make_uint4(0, 0, n.axis, leaf);
+        // DTree::mean() == 0 (dtree.rs:71-77) decides between uniform and tree sampling
+        const float mean = n.sampler.weight == 0.0f ? 0.0f : n.sampler.nodes[0].sum() / (kFourPi * n.sampler.weight);
+        out.leaf_info.push_back(make_uint4((uint32_t)out.s_rad.size(), (uint32_t)out.c_child.size(), mean == 0.0f ? 1u : 0u, 0u));
+        out.leaf_snode.push_back((uint32_t)i);
+        for (const HostDNode& d : n.sampler.nodes) {
+            out.s_rad.push_back(make_float4(d.rad[0], d.rad[1], d.rad[2], d.rad[3]));
+            out.s_child.push_back(pack_children(d));
+        }
+        for (const HostDNode& d : n.collector.nodes) out.c_child.push_back(pack_children(d));
+    }
+    out.n_collector_nodes = (uint32_t)out.c_child.size();
+}
+
+void HostSdTree::load_collector_stats(const SdTreeFlat& layout, const float* stats) {
+    const float* weights = stats + 4 * (size_t)layout.n_collector_nodes;
+    for (size_t leaf = 0; leaf < layout.leaf_snode.size(); leaf++) {
+        HostSNode& n = nodes[layout.leaf_snode[leaf]];
+        const float* r = stats + 4 * (size_t)layout.leaf_info[leaf].y;
+        for (size_t k = 0; k < n.collector.nodes.size(); k++)
+            for (int c = 0; c < 4; c++) n.collector.nodes[k].rad[c] = r[4 * k + c];
+        n.collector.weight = weights[leaf];
+    }
+}
+
+uint64_t HostSdTree::total_sampler_nodes() const {
+    uint64_t t = 0;
+    for (const HostSNode& n : nodes)
+        if (n.left == 0) t += n.sampler.nodes.size();
+    return t;
+}
+
+}  // namespace pt

@@ -1,0 +1,61 @@
+// sdtree_host.h — host side of the guided integrator's SD-tree (Müller et al.): the structure lives here between
+// waves, is refined here ("between training iterations the tree is refined on the host") and is flattened into
+// two arenas for the device: a read-only sampling copy and a collector that the record kernel splats into.
+// Restates pt/src/integrator/path_guiding/stree.rs:21-101,255-260 and dtree.rs:185-198,291-328,378-418.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "pt_types.h"
+
+namespace pt {
+
+struct HostDNode {  // DTreeNode (dtree.rs:28-32): 4 child sums + 4 child links (0 = leaf child)
+    float rad[4] = {0, 0, 0, 0};
+    uint16_t child[4] = {0, 0, 0, 0};
+    float sum() const { return ((0.0f + rad[0]) + rad[1] + rad[2]) + rad[3]; }
+};
+struct HostDTree {
+    float weight = 0.0f;  // statistical_weight
+    std::vector<HostDNode> nodes;
+    std::vector<uint16_t> free_slots;
+    void reset_root() {
+        weight = 0.0f;
+        nodes.assign(1, HostDNode{});
+        free_slots.clear();
+    }
+};
+struct HostSNode {  // STreeNode (stree.rs:12-19)
+    HostDTree sampler, collector;
+    uint32_t left = 0, right = 0;  // 0 = leaf
+    uint32_t axis = 0, depth = 0;
+};
+
+// Flat device image of the tree (see pt_guided.h for how the kernels read it).
+struct SdTreeFlat {
+    std::vector<uint4> snodes;          // {left, right, axis, leaf_id}
+    std::vector<uint4> leaf_info;       // per leaf: {sampler node offset, collector node offset, mean_is_zero, 0}
+    std::vector<float4> s_rad;          // sampler arena
+    std::vector<uint2> s_child;
+    std::vector<uint2> c_child;         // collector arena topology (sums start at zero on the device)
+    std::vector<uint32_t> leaf_snode;   // leaf id -> STree node index
+    uint32_t n_collector_nodes = 0;
+};
+
+struct HostSdTree {
+    std::vector<HostSNode> nodes;
+    Box3 bounds;
+    // STree::new (stree.rs:21-34): cube around the scene bounds' centroid with side = largest extent.
+    void init(V3 scene_lo, V3 scene_hi);
+    // STree::new_iteration (stree.rs:42-54): subdivide_nodes, then per leaf build -> emit_into(sampler) -> subdivide_and_clear.
+    // Returns false (and sets err) if a DTree would need more than 65535 nodes (u16 links, dtree.rs:18,395).
+    bool new_iteration(float directional_threshold, float spatial_threshold, uint32_t iteration, std::string* err);
+    void flatten(SdTreeFlat& out) const;
+    // Collector statistics as the device accumulated them: stats = [rad of every collector node (4 floats each) ...,
+    // weight of every leaf ...] in the layout flatten() produced.
+    void load_collector_stats(const SdTreeFlat& layout, const float* stats);
+    uint64_t total_sampler_nodes() const;
+};
+
+}  // namespace pt

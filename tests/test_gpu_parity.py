@@ -182,3 +182,87 @@ def test_error_paths(gpu_ctx):
         gpu_ctx.render(pt.make_integrator(7, 4, 0), 1)
     with pytest.raises(pt.PtError):
         gpu_ctx.render(pt.make_integrator(pt.INTEGRATOR_PATH, 4, pt.MODE_MIS), 4, shard_index=3, shard_count=2)
+
+
+# ------------------------------------------------------------------ guided integrator
+def test_guided_first_wave_equals_oracle(gpu_ctx):
+    """Wave 0 has no tree yet: plain BSDF sampling, path for path the oracle's walk (and it seeds the SD-tree)."""
+    sc = pt.LoadedScene("cornell-box-guided", resx=64, resy=64, max_depth=8)
+    o = ob.OracleScene(sc)
+    gpu_ctx.load(sc)
+    gf, gs, gst = gpu_ctx.render(sc.integrator, 1)
+    cf, cs, cst = o.render(sc.camera, sc.integrator, 1)
+    assert gs == cs == 1.0
+    rel = np.abs(gf - cf).sum(axis=2) / (np.abs(cf).sum(axis=2) + 1e-6)
+    assert (rel < 1e-3).mean() > 0.99
+    assert gst["extend_rays"] == cst["extend_rays"] and gst["shadow_rays"] == cst["shadow_rays"]
+
+
+def test_guided_furnace_matches_the_reference_energy_loss(gpu_ctx):
+    """See tests/test_oracle_cpu.py: the reference's guided walk loses the vertex whose tree-sampled direction the BSDF
+    rejects, so its furnace converges to ~0.81 instead of 1. The GPU must land on the oracle's number, not on 1."""
+    sc = su.furnace_scene("plain")
+    gpu_ctx.set_scene(sc)
+    o = ob.OracleScene(sc)
+    cam = pt.make_camera(su.IDENTITY, 19.5, 16, 16)
+    gpu_ctx.set_camera(cam)
+    integ = pt.make_integrator(pt.INTEGRATOR_GUIDED, 16, pt.MODE_MIS)
+    # the loss shrinks as the tree localises, so both sides must train on the same number of samples
+    gf, gs, gst = gpu_ctx.render(integ, 255)
+    cf, cs, cst = o.render(cam, integ, 255)
+    g, c = (gf * gs).mean(), (cf * cs).mean()
+    assert 0.75 < c < 0.95 and abs(g - c) < 0.01, (g, c)
+    assert gst["stree_nodes"] == cst["stree_nodes"]
+
+
+@pytest.mark.parametrize("name,res,spp,depth", [("cornell-box-guided", (64, 64), 63, 8), ("veach-bidir", (64, 64), 31, 8)])
+def test_guided_image_and_tree_match_oracle(gpu_ctx, name, res, spp, depth):
+    """Same scene, spp and RNG streams. Atomic splat order differs (f32), and one flipped decision changes what a leaf
+    learns, so trees and images agree statistically: image means within 2 %, block-averaged relMSE small, SD-tree
+    sizes within 15 %."""
+    sc = pt.LoadedScene(name, resx=res[0], resy=res[1], max_depth=depth, integrator="guided")
+    o = ob.OracleScene(sc)
+    gpu_ctx.load(sc)
+    integ = pt.IntegratorDesc.from_buffer_copy(sc.integrator)
+    integ.spatial_threshold = 200.0   # make the small test image split the spatial tree several times
+    gf, gs, gst = gpu_ctx.render(integ, spp)
+    cf, cs, cst = o.render(sc.camera, integ, spp)
+    assert gs == cs
+    g, c = gf * gs, cf * cs
+    k = 8
+    gb = g.reshape(res[1] // k, k, res[0] // k, k, 3).mean(axis=(1, 3))
+    cb = c.reshape(res[1] // k, k, res[0] // k, k, 3).mean(axis=(1, 3))
+    assert cst["stree_nodes"] > 3
+    assert abs(gst["stree_nodes"] - cst["stree_nodes"]) <= 0.15 * cst["stree_nodes"] + 2, (gst["stree_nodes"], cst["stree_nodes"])
+    assert abs(gst["dtree_nodes"] - cst["dtree_nodes"]) <= 0.15 * cst["dtree_nodes"] + 8, (gst["dtree_nodes"], cst["dtree_nodes"])
+    assert abs(np.median(gb) / np.median(cb) - 1.0) < 0.05
+    assert abs(gst["extend_rays"] / cst["extend_rays"] - 1.0) < 0.02
+    assert ob.rel_mse(np.minimum(gb, 5.0), np.minimum(cb, 5.0)) < 0.05
+
+
+def test_guided_wave_api_and_stats_buffer(gpu_ctx):
+    """begin -> wave(0..n-1) -> end equals ptgpu_render; the statistics buffer is exposed between waves."""
+    sc = pt.LoadedScene("cornell-box-guided", resx=32, resy=32, max_depth=6)
+    gpu_ctx.load(sc)
+    n = gpu_ctx.guided_begin(sc.integrator, 15)
+    assert n == 4
+    sizes = []
+    for w in range(n):
+        gpu_ctx.guided_wave(w)
+        ptr, count = gpu_ctx.guided_stats()
+        assert ptr and count >= 5
+        sizes.append(count)
+    film, scale, st = gpu_ctx.guided_end()
+    assert scale == 1.0 / 8.0 and st["samples"] == 32 * 32 * 15 and sizes[-1] >= sizes[0]
+    with pytest.raises(pt.PtError):
+        gpu_ctx.guided_wave(0)   # no begin
+
+
+def test_guided_shards_cover_every_sample_once(gpu_ctx):
+    sc = pt.LoadedScene("cornell-box-guided", resx=48, resy=40, max_depth=4)   # ragged tiles: 48x40 = 3x3 tiles, last row 8 high
+    gpu_ctx.load(sc)
+    total = 0
+    for k in range(3):
+        _, _, st = gpu_ctx.render(sc.integrator, 7, k, 3)
+        total += st["samples"]
+    assert total == 48 * 40 * 7
