@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark: Msamples/s of the `guided` integrator on cornell-box-guided (BASELINE.json metric,
+configs[3]: 512x512, 512 spp per GPU, max_depth 16, SD-tree statistics all-reduced over RCCL after each wave).
+
+    python bench.py --gpus N --steps K --warmup W [--workload guided|path|veach-mis|lightpath]
+
+A "step" is one complete render of the workload through the C ABI (all waves, host refinement included). With N > 1
+(launched by torch.distributed.run, one rank per GPU) every rank traces its share of each wave's (pass, tile) pairs,
+the collector statistics are summed with an RCCL all-reduce after every wave and the films with one reduce at the
+end. Scaling is WEAK: the sample budget grows with N (spp = 512 * N), per-GPU work stays at 512 spp worth of paths.
+Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+REPO = Path(__file__).resolve().parent
+sys.path.insert(0, str(REPO))
+sys.path.insert(0, str(REPO / "tests"))
+
+import numpy as np  # noqa: E402
+
+WORKLOADS = {
+    # name: (scene, integrator override, resx, resy, spp per GPU, max_depth)
+    "guided": ("cornell-box-guided", "guided", 512, 512, 512, 16),     # BASELINE configs[3] (shipped XML values)
+    "path": ("cornell-box", "path", 512, 512, 64, 8),                  # configs[0]
+    "veach-mis": ("veach-mis", "path", 1280, 720, 1024, 3),            # configs[1]
+    "lightpath": ("cornell-box", "lightpath", 512, 512, 512, 16),      # configs[2]
+}
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+class DeviceArray:
+    """Raw device pointer -> torch tensor (zero copy) through __cuda_array_interface__."""
+
+    def __init__(self, ptr, count):
+        self.__cuda_array_interface__ = {"shape": (count,), "typestr": "<f4", "data": (ptr, False), "version": 2}
+
+
+def main() -> int:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="guided", choices=sorted(WORKLOADS))
+    ap.add_argument("--spp", type=int, default=0, help="override spp per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--census", action="store_true", help="also count BVH nodes/triangles per ray (extra untimed render)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import path_tracer_amd as pt
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if world != args.gpus and rank == 0:
+        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    scene_name, integrator, resx, resy, spp_per_gpu, max_depth = WORKLOADS[args.workload]
+    if args.spp:
+        spp_per_gpu = args.spp
+    spp = spp_per_gpu * world  # weak scaling: the sample budget grows with the number of GPUs
+    sc = pt.LoadedScene(scene_name, resx=resx, resy=resy, spp=spp, max_depth=max_depth, integrator=integrator)
+    ctx = pt.Context(local_rank)
+    ctx.load(sc)
+    integ = pt.IntegratorDesc.from_buffer_copy(sc.integrator)
+    guided = integ.kind == pt.INTEGRATOR_GUIDED
+    film_dev = torch.zeros((resy, resx, 3), dtype=torch.float64, device=dev) if world > 1 else None
+
+    def step():
+        """One render of the whole workload; returns (film sums on rank 0, film_scale, stats of this rank)."""
+        if guided:
+            n_waves = ctx.guided_begin(integ, spp, rank, world)
+            for w in range(n_waves):
+                ctx.guided_wave(w)
+                if world > 1 and w + 1 < n_waves:
+                    ptr, count = ctx.guided_stats()
+                    t = torch.as_tensor(DeviceArray(ptr, count), device=dev)
+                    dist.all_reduce(t, op=dist.ReduceOp.SUM)   # RCCL over xGMI, in place on the library's buffer
+                    torch.cuda.synchronize(dev)
+            film, scale, st = ctx.guided_end()
+        else:
+            film, scale, st = ctx.render(integ, spp, rank, world)
+        if world > 1:
+            film_dev.copy_(torch.from_numpy(film))
+            dist.reduce(film_dev, dst=0, op=dist.ReduceOp.SUM)
+            torch.cuda.synchronize(dev)
+            if rank == 0:
+                film = film_dev.cpu().numpy()
+        return film, scale, st
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    ctx.set_profiling(True)  # HIP-event pairs on the library's own stream, recorded without host waits
+    stage_ms = {k: 0.0 for k in pt.KERNEL_NAMES}
+    stage_n = {k: 0 for k in pt.KERNEL_NAMES}
+    totals = {"samples": 0, "extend_rays": 0, "shadow_rays": 0, "segments": 0}
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        film, scale, st = step()
+        for k in totals:
+            totals[k] += st[k]
+        for k, (ms, n) in ctx.kernel_times().items():
+            stage_ms[k] += ms
+            stage_n[k] += n
+    fence()
+    elapsed = time.perf_counter() - t0
+    ctx.set_profiling(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        tot = torch.tensor([totals[k] for k in ("samples", "extend_rays", "shadow_rays", "segments")], dtype=torch.float64, device=dev)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        for i, k in enumerate(("samples", "extend_rays", "shadow_rays", "segments")):
+            totals[k] = int(tot[i].item())
+
+    if rank != 0:
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return 0
+
+    samples = resx * resy * spp * args.steps
+    assert totals["samples"] == samples, (totals["samples"], samples)
+    value = samples / elapsed * 1e-6
+    mrays = (totals["extend_rays"] + totals["shadow_rays"]) / elapsed * 1e-6
+
+    # ---- roofline of the dominant kernel (rank 0's launches, HIP events over the timed region)
+    kernel_stages = [k for k in ("raygen", "extend", "shade", "occlude", "guide_record") if stage_n[k] > 0]
+    dom = max(kernel_stages, key=lambda k: stage_ms[k])
+    my_segments = st["segments"] * args.steps
+    my_extend = st["extend_rays"] * args.steps
+    my_shadow = st["shadow_rays"] * args.steps
+    census = None
+    if world == 1 and (args.census or dom in ("extend", "occlude")):
+        ctx.set_census(True)   # instrumented kernel variants, one extra untimed render
+        step()
+        census = ctx.census()
+        ctx.set_census(False)
+    # algorithmic bytes per unit (DESIGN.md "Kernels and rooflines"; SURVEY.md §8d split per stage)
+    if dom == "shade":
+        # per shaded segment: path state read + write (2 x 128 B), hit read 16 B, next ray write 32 B, shadow ray write 36 B per
+        # NEE sample, and for guided one 128-B PathVertex per segment (tree node reads not counted: conservative)
+        alg_bytes = my_segments * (2 * 128 + 16 + 32 + (128 if guided else 0)) + my_shadow * 36
+    elif dom == "extend":
+        per_ray = 32 + 16
+        if census:
+            per_ray += (32 * census["extend_nodes"] + 36 * census["extend_tris"]) / max(1, st["extend_rays"])
+        alg_bytes = my_extend * per_ray
+    elif dom == "occlude":
+        per_ray = 36 + 64
+        if census:
+            per_ray += (32 * census["occlude_nodes"] + 36 * census["occlude_tris"]) / max(1, st["shadow_rays"])
+        alg_bytes = my_shadow * per_ray
+    elif dom == "guide_record":
+        alg_bytes = my_segments * (128 + 4 * 8)
+    else:
+        alg_bytes = st["samples"] * args.steps * 128
+    launches = max(1, stage_n[dom])
+    avg_ms = stage_ms[dom] / launches
+    achieved = alg_bytes / launches / (avg_ms * 1e-3) * 1e-9 if avg_ms > 0 else 0.0
+    roofline = {"bound": "hbm", "kernel": {"extend": "k_extend", "shade": "k_shade_guided" if guided else ("k_shade_light" if integ.kind == pt.INTEGRATOR_LIGHTPATH else "k_shade_path"),
+                                           "occlude": "k_occlude", "guide_record": "k_guide_record", "raygen": "k_raygen"}[dom],
+                "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                "avg_launch_ms": round(avg_ms, 4), "launches": launches, "alg_bytes_per_launch": int(alg_bytes / launches),
+                "stage_ms_per_step": {k: round(stage_ms[k] / args.steps, 2) for k in stage_ms if stage_n[k]}}
+    if census:
+        roofline["census"] = {"nodes_per_extend_ray": round(census["extend_nodes"] / max(1, st["extend_rays"]), 2),
+                              "tris_per_extend_ray": round(census["extend_tris"] / max(1, st["extend_rays"]), 2),
+                              "nodes_per_shadow_ray": round(census["occlude_nodes"] / max(1, st["shadow_rays"]), 2),
+                              "tris_per_shadow_ray": round(census["occlude_tris"] / max(1, st["shadow_rays"]), 2)}
+
+    # ---- CPU baseline: the oracle (a port of the reference's algorithm), bounded sample, rank 0 at N=1 only
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline:
+        import oracle_bind as ob
+        cores = min(16, os.cpu_count() or 1)
+        cpu_spp = {"guided": 15, "path": 8, "veach-mis": 8, "lightpath": 8}[args.workload]
+        o = ob.OracleScene(sc)
+        t0 = time.perf_counter()
+        _, _, cst = o.render(sc.camera, integ, cpu_spp, n_threads=cores)
+        dt = time.perf_counter() - t0
+        cpu = {"value": round(cst["samples"] / dt * 1e-6, 4), "unit": "Msamples/s", "cores": cores, "kind": "port",
+               "sample": f"{scene_name} {resx}x{resy} @ {cpu_spp} spp, {integrator}, max_depth {max_depth} ({dt:.1f} s; C++ restatement of the reference, "
+                         "the Rust reference cannot be built in this image)"}
+
+    out = {
+        "metric": "Msamples/s", "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{scene_name}, integrator={integrator}, {resx}x{resy} @ {spp_per_gpu} spp per GPU ({spp} total), max_depth {max_depth}",
+                   "parallelism": f"shard{world}: (pass, tile) pairs round-robin, RCCL all-reduce of SD-tree statistics per wave" if guided else f"shard{world}: sample index mod N",
+                   "mrays_per_s": round(mrays, 1), "stree_nodes": st.get("stree_nodes", 0), "dtree_nodes": st.get("dtree_nodes", 0)},
+        "roofline": roofline, "cpu_baseline": cpu,
+    }
+    print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

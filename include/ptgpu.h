@@ -155,14 +155,18 @@ int ptgpu_occluded_batch(ptgpu_ctx* ctx, const float* from, const float* to, uin
 int ptgpu_scene_info(ptgpu_ctx* ctx, uint32_t* n_nodes, uint32_t* n_tris, uint32_t* n_emissive_tris, float bounds_out[6]);
 int ptgpu_scene_bvh(ptgpu_ctx* ctx, uint32_t* nodes_out, uint32_t* leaf_tris_out);
 
-/* Timing hook for bench.py: when enabled, every kernel launch is bracketed by HIP events on the library's
- * stream and the per-stage sums are reported in ptgpu_stats (adds a sync per launch batch; off by default). */
+/* Timing hook for bench.py: when enabled, every kernel launch is bracketed by a pair of HIP events on the library's
+ * stream (recorded without waiting, resolved at the end of the call); per-stage sums via ptgpu_kernel_times. */
 int ptgpu_set_profiling(ptgpu_ctx* ctx, int enabled);
 /* Per-stage totals of the last render call (valid when profiling was enabled): ms_out[i] = summed HIP-event time of
  * the launches of stage i, launches_out[i] = their number; i = PTGPU_STAGE_*; n = entries available in the arrays. */
 enum { PTGPU_STAGE_RAYGEN = 0, PTGPU_STAGE_EXTEND = 1, PTGPU_STAGE_SHADE = 2, PTGPU_STAGE_OCCLUDE = 3, PTGPU_STAGE_RECORD = 4,
        PTGPU_STAGE_OTHER = 5, PTGPU_N_STAGES = 6 };
 int ptgpu_kernel_times(ptgpu_ctx* ctx, double* ms_out, uint64_t* launches_out, uint32_t n);
+/* Traversal census for roofline accounting (bench only; selects instrumented kernel variants, off by default):
+ * out[0..3] = BVH nodes visited / triangles tested by extend rays, then by occlusion rays, since it was enabled. */
+int ptgpu_set_census(ptgpu_ctx* ctx, int enabled);
+int ptgpu_census(ptgpu_ctx* ctx, uint64_t out[4]);
 /* Paths kept in flight per batch (state SoA size); 0 restores the default. */
 int ptgpu_set_batch_paths(ptgpu_ctx* ctx, uint32_t n_paths);
 

@@ -81,7 +81,7 @@ PTGPU_SYMBOLS = [
     "ptgpu_last_error", "ptgpu_init", "ptgpu_destroy", "ptgpu_scene_create", "ptgpu_camera_set", "ptgpu_render",
     "ptgpu_render_shard", "ptgpu_guided_begin", "ptgpu_guided_wave", "ptgpu_guided_stats", "ptgpu_guided_end",
     "ptgpu_trace_batch", "ptgpu_occluded_batch", "ptgpu_scene_info", "ptgpu_scene_bvh", "ptgpu_set_profiling",
-    "ptgpu_set_batch_paths", "ptgpu_kernel_times",
+    "ptgpu_set_batch_paths", "ptgpu_kernel_times", "ptgpu_set_census", "ptgpu_census",
 ]
 PTHOST_SYMBOLS = [
     "pthost_last_error", "pthost_scene_load", "pthost_scene_free", "pthost_scene_desc", "pthost_camera_desc",
@@ -147,6 +147,8 @@ def load_gpu() -> C.CDLL:
         lib.ptgpu_scene_bvh.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         lib.ptgpu_set_profiling.argtypes = [C.c_void_p, C.c_int]
         lib.ptgpu_set_batch_paths.argtypes = [C.c_void_p, C.c_uint32]
+        lib.ptgpu_set_census.argtypes = [C.c_void_p, C.c_int]
+        lib.ptgpu_census.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
         lib.ptgpu_kernel_times.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_uint32]
         _gpu = lib
     return _gpu
@@ -307,6 +309,14 @@ class Context:
 
     def set_batch_paths(self, n: int):
         self._check(self.lib.ptgpu_set_batch_paths(self.handle, n))
+
+    def set_census(self, on: bool):
+        self._check(self.lib.ptgpu_set_census(self.handle, 1 if on else 0))
+
+    def census(self):
+        out = (C.c_uint64 * 4)()
+        self._check(self.lib.ptgpu_census(self.handle, out))
+        return {"extend_nodes": out[0], "extend_tris": out[1], "occlude_nodes": out[2], "occlude_tris": out[3]}
 
     def kernel_times(self):
         """{stage: (total_ms, launches)} of the last render with profiling on."""

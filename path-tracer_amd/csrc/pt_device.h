@@ -367,8 +367,9 @@ PT_D Hit bvh_intersect(const SceneDev& sc, V3 o, V3 d, float ray_end_t, uint32_t
     return best;
 }
 // Scene::occluded (scene.rs:229-235): unnormalised segment, t_max 0.9999, full closest-hit like Bvh::hit.
-PT_D bool scene_occluded(const SceneDev& sc, V3 from, V3 to) {
-    Hit h = bvh_intersect<false>(sc, from, to - from, 0.9999f, nullptr, nullptr);
+template <bool COUNT = false>
+PT_D bool scene_occluded(const SceneDev& sc, V3 from, V3 to, uint32_t* n_nodes = nullptr, uint32_t* n_tris = nullptr) {
+    Hit h = bvh_intersect<COUNT>(sc, from, to - from, 0.9999f, n_nodes, n_tris);
     return h.prim != kNoHit;
 }
 

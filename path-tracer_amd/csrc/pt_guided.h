@@ -448,17 +448,20 @@ __global__ __launch_bounds__(kBlock) void k_shade_guided(SceneDev sc, SdTreeDev 
 }
 
 // NEE visibility for the guided walk: an unoccluded sample becomes the vertex's li_sample_contribution.
-__global__ __launch_bounds__(kBlock) void k_occlude_guided(SceneDev sc, GuidedParams gp, ShadowCols sh, const RoundCounters* cnt) {
+template <bool CENSUS>
+__global__ __launch_bounds__(kBlock) void k_occlude_guided(SceneDev sc, GuidedParams gp, ShadowCols sh, const RoundCounters* cnt, unsigned long long* census) {
     const uint32_t n = cnt->n_shadow;
     const uint32_t stride = gridDim.x * blockDim.x;
+    uint32_t cn = 0, ct = 0;
     for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) {
         const float4 a = sh.q0[j], b = sh.q1[j];
-        if (!scene_occluded(sc, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z))) {
+        if (!scene_occluded<CENSUS>(sc, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), &cn, &ct)) {
             const size_t k = (size_t)f2u(b.w) * gp.row_stride + f2u(a.w);
             gp.vtx.li0[k] = sh.q2[j];
             gp.vtx.li1[k] = sh.q3[j];
         }
     }
+    if (CENSUS) census_add(census, 2, cn, ct);
 }
 
 // Back-to-front pass over each finished path (mod.rs:106-116): what arrives at a vertex from further along the path

@@ -25,6 +25,20 @@ PT_D void wave_count(uint32_t* counter, bool want) {
     if (mask != 0ull && (int)__lane_id() == __ffsll((long long)mask) - 1) atomicAdd(counter, (uint32_t)__popcll(mask));
 }
 
+// Traversal census (bench / roofline accounting only): per-lane node and triangle counts summed into
+// census[base + 0] and census[base + 1]. Compiled out of the production instantiations.
+PT_D void census_add(unsigned long long* census, int base, uint32_t nodes, uint32_t tris) {
+    unsigned long long a = nodes, b = tris;
+    for (int off = 32; off > 0; off >>= 1) {
+        a += __shfl_down(a, off);
+        b += __shfl_down(b, off);
+    }
+    if (__lane_id() == 0) {
+        atomicAdd(census + base, a);
+        atomicAdd(census + base + 1, b);
+    }
+}
+
 PT_D Spec load_spec(const float4* a, const float4* b, uint32_t i) {
     const float4 x = a[i], y = b[i];
     Spec s;
@@ -87,15 +101,18 @@ __global__ __launch_bounds__(kBlock) void k_raygen_camera(SceneDev sc, CameraDev
 
 // ------------------------------------------------------------------ extend (closest hit)
 // Scene::intersect -> Bvh::intersect (scene.rs:184-186, bvh.rs:86-142) for slots [0, n_active).
-__global__ __launch_bounds__(kBlock) void k_extend(SceneDev sc, PathCols st, HitCols hit, const RoundCounters* cnt) {
+template <bool CENSUS>
+__global__ __launch_bounds__(kBlock) void k_extend(SceneDev sc, PathCols st, HitCols hit, const RoundCounters* cnt, unsigned long long* census) {
     const uint32_t n = cnt->n_active;
     const uint32_t stride = gridDim.x * blockDim.x;
+    uint32_t cn = 0, ct = 0;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const float4 o = st.o_pdf[i], d = st.d_flags[i];
-        const Hit h = bvh_intersect<false>(sc, mk3(o.x, o.y, o.z), mk3(d.x, d.y, d.z), f_inf(), nullptr, nullptr);
+        const Hit h = bvh_intersect<CENSUS>(sc, mk3(o.x, o.y, o.z), mk3(d.x, d.y, d.z), f_inf(), &cn, &ct);
         hit.tb[i] = make_float4(h.th.t, h.th.b0, h.th.b1, h.th.b2);
         hit.prim[i] = h.prim;
     }
+    if (CENSUS) census_add(census, 0, cn, ct);
 }
 
 // Parity hook: caller-supplied rays (ox,oy,oz,dx,dy,dz,tmax) -> ptgpu_hit-shaped records + traversal counts.
@@ -288,12 +305,14 @@ __global__ __launch_bounds__(kBlock) void k_shade_path(SceneDev sc, RenderParams
 // ------------------------------------------------------------------ occlude: `path` integrator
 // Scene::occluded for the NEE shadow rays of this round; adds the MIS-weighted contribution to the path's
 // radiance and finishes paths that ended in shade with this ray still pending.
-__global__ __launch_bounds__(kBlock) void k_occlude_path(SceneDev sc, RenderParams rp, PathCols st, ShadowCols sh, const RoundCounters* cnt) {
+template <bool CENSUS>
+__global__ __launch_bounds__(kBlock) void k_occlude_path(SceneDev sc, RenderParams rp, PathCols st, ShadowCols sh, const RoundCounters* cnt, unsigned long long* census) {
     const uint32_t n = cnt->n_shadow;
     const uint32_t stride = gridDim.x * blockDim.x;
+    uint32_t cn = 0, ct = 0;
     for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) {
         const float4 a = sh.q0[j], b = sh.q1[j];
-        const bool occ = scene_occluded(sc, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z));
+        const bool occ = scene_occluded<CENSUS>(sc, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), &cn, &ct);
         const uint32_t target = f2u(a.w);
         const uint32_t slot = target & ~kTerminalBit;
         if (target & kTerminalBit) {
@@ -310,6 +329,7 @@ __global__ __launch_bounds__(kBlock) void k_occlude_path(SceneDev sc, RenderPara
             store_spec(st.L0, st.L1, slot, L);
         }
     }
+    if (CENSUS) census_add(census, 2, cn, ct);
 }
 
 // ------------------------------------------------------------------ lightpath integrator
@@ -464,17 +484,20 @@ __global__ __launch_bounds__(kBlock) void k_shade_light(SceneDev sc, CameraDev c
 }
 
 // Camera-connection visibility + Film::add_splat (camera.rs:161-166) with f64 atomics.
-__global__ __launch_bounds__(kBlock) void k_occlude_splat(SceneDev sc, RenderParams rp, ShadowCols sh, const RoundCounters* cnt) {
+template <bool CENSUS>
+__global__ __launch_bounds__(kBlock) void k_occlude_splat(SceneDev sc, RenderParams rp, ShadowCols sh, const RoundCounters* cnt, unsigned long long* census) {
     const uint32_t n = cnt->n_shadow;
     const uint32_t stride = gridDim.x * blockDim.x;
     const double* r = reinterpret_cast<const double*>(sh.q2);
+    uint32_t cn = 0, ct = 0;
     for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) {
         const float4 a = sh.q0[j], b = sh.q1[j];
-        if (!scene_occluded(sc, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z))) {
+        if (!scene_occluded<CENSUS>(sc, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), &cn, &ct)) {
             const double rgb[3] = {r[3 * (size_t)j], r[3 * (size_t)j + 1], r[3 * (size_t)j + 2]};
             film_add_rgb(rp.film, f2u(a.w), rgb);
         }
     }
+    if (CENSUS) census_add(census, 2, cn, ct);
 }
 
 }  // namespace pt

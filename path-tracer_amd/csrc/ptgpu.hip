@@ -104,7 +104,12 @@ struct ptgpu_ctx {
     DevBuf<float> d_lambda_u;
     std::vector<RoundCounters> h_counters;
     bool profiling = false;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // HIP-event pool: each launch records a start/stop pair on the library's stream without waiting; the pairs are
+    // resolved once per render call, so profiling does not serialise the host with the device.
+    std::vector<hipEvent_t> ev_pool;
+    std::vector<int> ev_stage;  // stage of pair i (events 2i, 2i+1)
+    bool census_on = false;
+    DevBuf<unsigned long long> d_census;  // extend nodes, extend tris, occlude nodes, occlude tris
     double stage_ms[PTGPU_N_STAGES] = {0, 0, 0, 0, 0, 0};
     uint64_t stage_launches[PTGPU_N_STAGES] = {0, 0, 0, 0, 0, 0};
     uint64_t launches = 0;
@@ -143,31 +148,45 @@ ShadowCols shadow_view(ptgpu_ctx* c) {
     return s;
 }
 
-// Brackets one kernel launch with HIP events on the library's stream when profiling is on.
+// Brackets one kernel launch with a pair of HIP events on the library's stream when profiling is on.
 struct StageTimer {
     ptgpu_ctx* c;
     int stage;
+    size_t pair = 0;
+    bool on = false;
     StageTimer(ptgpu_ctx* c_, int stage_) : c(c_), stage(stage_) {
-        if (c->profiling) (void)hipEventRecord(c->ev0, c->stream);
+        if (!c->profiling) return;
+        pair = c->ev_stage.size();
+        while (c->ev_pool.size() < 2 * (pair + 1)) {
+            hipEvent_t e = nullptr;
+            if (hipEventCreate(&e) != hipSuccess) return;
+            c->ev_pool.push_back(e);
+        }
+        c->ev_stage.push_back(stage);
+        on = true;
+        (void)hipEventRecord(c->ev_pool[2 * pair], c->stream);
     }
     ~StageTimer() {
         c->launches++;
         c->stage_launches[stage]++;
-        if (c->profiling) {
-            (void)hipEventRecord(c->ev1, c->stream);
-            (void)hipEventSynchronize(c->ev1);
-            float ms = 0.0f;
-            (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
-            c->stage_ms[stage] += ms;
-        }
+        if (on) (void)hipEventRecord(c->ev_pool[2 * pair + 1], c->stream);
     }
 };
+// Turns the recorded event pairs into per-stage totals; call after the stream has been synchronised.
+void resolve_stage_times(ptgpu_ctx* c) {
+    for (size_t i = 0; i < c->ev_stage.size(); i++) {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, c->ev_pool[2 * i], c->ev_pool[2 * i + 1]) == hipSuccess) c->stage_ms[c->ev_stage[i]] += ms;
+    }
+    c->ev_stage.clear();
+}
 void reset_stage_times(ptgpu_ctx* c) {
     for (int i = 0; i < PTGPU_N_STAGES; i++) {
         c->stage_ms[i] = 0.0;
         c->stage_launches[i] = 0;
     }
     c->launches = 0;
+    c->ev_stage.clear();
 }
 
 // Wavelength tables. The reference draws the hero-wavelength sample from a per-pixel additive recurrence
@@ -207,8 +226,8 @@ int ptgpu_init(ptgpu_ctx** out, int device_id) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) c->n_cus = prop.multiProcessorCount;
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipEventCreate(&c->ev0);
-    if (e == hipSuccess) e = hipEventCreate(&c->ev1);
+    if (e == hipSuccess) e = c->d_census.alloc(4);
+    if (e == hipSuccess) e = hipMemset(c->d_census.p, 0, 4 * sizeof(unsigned long long));
     if (e == hipSuccess) e = c->d_d65.upload(std::vector<float>(kD65, kD65 + CIE_N), c->stream);
     if (e == hipSuccess) e = c->d_xyz.upload(std::vector<double>(&kXyz[0][0], &kXyz[0][0] + 3 * CIE_N), c->stream);
     if (e != hipSuccess) {
@@ -224,8 +243,7 @@ void ptgpu_destroy(ptgpu_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     guided_free(c->guided);
-    if (c->ev0) (void)hipEventDestroy(c->ev0);
-    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -458,6 +476,22 @@ int ptgpu_kernel_times(ptgpu_ctx* c, double* ms_out, uint64_t* launches_out, uin
     }
     return PTGPU_OK;
 }
+int ptgpu_set_census(ptgpu_ctx* c, int enabled) {
+    if (!c) return fail(PTGPU_E_INVALID, "set_census: NULL ctx");
+    HIP_TRY(hipSetDevice(c->device));
+    c->census_on = enabled != 0;
+    if (enabled) HIP_TRY(hipMemset(c->d_census.p, 0, 4 * sizeof(unsigned long long)));
+    return PTGPU_OK;
+}
+int ptgpu_census(ptgpu_ctx* c, uint64_t out[4]) {
+    if (!c || !out) return fail(PTGPU_E_INVALID, "census: NULL argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    unsigned long long h[4];
+    HIP_TRY(hipMemcpy(h, c->d_census.p, sizeof(h), hipMemcpyDeviceToHost));
+    for (int i = 0; i < 4; i++) out[i] = h[i];
+    return PTGPU_OK;
+}
 int ptgpu_set_batch_paths(ptgpu_ctx* c, uint32_t n_paths) {
     if (!c) return fail(PTGPU_E_INVALID, "set_batch_paths: NULL ctx");
     c->batch_paths = n_paths;
@@ -467,6 +501,11 @@ int ptgpu_set_batch_paths(ptgpu_ctx* c, uint32_t n_paths) {
 }  // extern "C"
 
 namespace {
+
+void launch_extend(ptgpu_ctx* c, int grid, const PathCols& A, const HitCols& H, const RoundCounters* cnt) {
+    if (c->census_on) hipLaunchKernelGGL(k_extend<true>, dim3(grid), dim3(kBlock), 0, c->stream, c->scene, A, H, cnt, c->d_census.p);
+    else hipLaunchKernelGGL(k_extend<false>, dim3(grid), dim3(kBlock), 0, c->stream, c->scene, A, H, cnt, c->d_census.p);
+}
 
 uint32_t pick_capacity(const ptgpu_ctx* c, uint64_t total_paths) {
     uint64_t cap = c->batch_paths ? c->batch_paths : (1ull << 22);
@@ -493,7 +532,8 @@ int run_batch_path_like(ptgpu_ctx* c, bool light, const RenderParams& rp, uint32
             hipLaunchKernelGGL(k_raygen_light, dim3(grid), dim3(kBlock), 0, c->stream, c->scene, c->camera, rp, A, S, cnt, n_paths, npix, first_sample, sample_step);
         }
         StageTimer t(c, PTGPU_STAGE_OCCLUDE);
-        hipLaunchKernelGGL(k_occlude_splat, dim3(grid), dim3(kBlock), 0, c->stream, c->scene, rp, S, cnt);
+        if (c->census_on) hipLaunchKernelGGL(k_occlude_splat<true>, dim3(grid), dim3(kBlock), 0, c->stream, c->scene, rp, S, cnt, c->d_census.p);
+        else hipLaunchKernelGGL(k_occlude_splat<false>, dim3(grid), dim3(kBlock), 0, c->stream, c->scene, rp, S, cnt, c->d_census.p);
     } else {
         StageTimer t(c, PTGPU_STAGE_RAYGEN);
         hipLaunchKernelGGL(k_raygen_camera, dim3(grid), dim3(kBlock), 0, c->stream, c->scene, c->camera, rp, A, cnt, n_paths, npix, first_sample, sample_step);
@@ -506,7 +546,7 @@ int run_batch_path_like(ptgpu_ctx* c, bool light, const RenderParams& rp, uint32
         if (round >= kMaxRounds) return fail(PTGPU_E_LIMIT, "render: more than 65536 wavefront rounds in one batch");
         {
             StageTimer t(c, PTGPU_STAGE_EXTEND);
-            hipLaunchKernelGGL(k_extend, dim3(grid), dim3(kBlock), 0, c->stream, c->scene, A, H, cnt + round);
+            launch_extend(c, grid, A, H, cnt + round);
         }
         {
             StageTimer t(c, PTGPU_STAGE_SHADE);
@@ -517,8 +557,13 @@ int run_batch_path_like(ptgpu_ctx* c, bool light, const RenderParams& rp, uint32
         }
         {
             StageTimer t(c, PTGPU_STAGE_OCCLUDE);
-            if (light) hipLaunchKernelGGL(k_occlude_splat, dim3(grid), dim3(kBlock), 0, c->stream, c->scene, rp, S, cnt + round + 1);
-            else hipLaunchKernelGGL(k_occlude_path, dim3(grid), dim3(kBlock), 0, c->stream, c->scene, rp, B, S, cnt + round + 1);
+            if (light) {
+                if (c->census_on) hipLaunchKernelGGL(k_occlude_splat<true>, dim3(grid), dim3(kBlock), 0, c->stream, c->scene, rp, S, cnt + round + 1, c->d_census.p);
+                else hipLaunchKernelGGL(k_occlude_splat<false>, dim3(grid), dim3(kBlock), 0, c->stream, c->scene, rp, S, cnt + round + 1, c->d_census.p);
+            } else {
+                if (c->census_on) hipLaunchKernelGGL(k_occlude_path<true>, dim3(grid), dim3(kBlock), 0, c->stream, c->scene, rp, B, S, cnt + round + 1, c->d_census.p);
+                else hipLaunchKernelGGL(k_occlude_path<false>, dim3(grid), dim3(kBlock), 0, c->stream, c->scene, rp, B, S, cnt + round + 1, c->d_census.p);
+            }
         }
         HIP_TRY(hipGetLastError());
         std::swap(A, B);
@@ -616,6 +661,7 @@ int ptgpu_render_shard(ptgpu_ctx* c, const ptgpu_integrator_desc* integ, uint32_
     if (rc != PTGPU_OK) return rc;
     rc = download_film(c, film_rgb_out);
     if (rc != PTGPU_OK) return rc;
+    resolve_stage_times(c);
     if (film_scale_out) *film_scale_out = 1.0 / (double)spp;  // Integrator::film_scale (integrator/mod.rs:47-50)
     if (stats) {
         stats->render_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();

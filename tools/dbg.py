@@ -1,17 +1,17 @@
 import sys, time
 sys.path.insert(0,'.'); sys.path.insert(0,'tests')
-import numpy as np, path_tracer_amd as pt, scenes_util as su, oracle_bind as ob
+import numpy as np, path_tracer_amd as pt
 ctx = pt.Context(0)
-for name, kind, res, spp, ov in [("cornell-box", pt.INTEGRATOR_PATH, (128,128), 64, dict(max_depth=8)),
-                                 ("veach-mis", pt.INTEGRATOR_PATH, (160,96), 64, {}),
-                                 ("veach-bidir", pt.INTEGRATOR_PATH, (128,128), 32, {}),
-                                 ("cornell-box", pt.INTEGRATOR_LIGHTPATH, (128,128), 64, dict(max_depth=8))]:
-    sc = pt.LoadedScene(name, resx=res[0], resy=res[1], **ov)
-    o = ob.OracleScene(sc); ctx.load(sc)
-    integ = pt.IntegratorDesc.from_buffer_copy(sc.integrator); integ.kind = kind
-    t=time.time(); gf, gs, gst = ctx.render(integ, spp); tg=time.time()-t
-    t=time.time(); cf, cs, cst = o.render(sc.camera, integ, spp); tc=time.time()-t
-    g, c = gf*gs, cf*cs
-    rel = np.abs(g-c).sum(axis=2)/(np.abs(c).sum(axis=2)+1e-6)
-    print(name, kind, "gpu %.3fs cpu %.3fs"%(tg,tc), "means", g.mean(), c.mean(), "median rel", np.median(rel), "p90", np.percentile(rel,90), "p99", np.percentile(rel,99), "frac<1e-3", (rel<1e-3).mean(),
-          "rays", gst["extend_rays"], cst["extend_rays"], gst["shadow_rays"], cst["shadow_rays"], gst["segments"], cst["segments"])
+def run(name, spp, prof, **ov):
+    sc = pt.LoadedScene(name, **ov); ctx.load(sc)
+    ctx.set_profiling(prof)
+    t=time.time(); f, s, st = ctx.render(sc.integrator, spp); dt=time.time()-t
+    print(f"{name} {ov} spp={spp} prof={prof}: {dt:.3f}s {st['samples']/dt*1e-6:.1f} Msamples/s {(st['extend_rays']+st['shadow_rays'])/dt*1e-6:.1f} Mrays/s launches={st['kernel_launches']} stree={st['stree_nodes']} dtree={st['dtree_nodes']} mean={(f*s).mean():.4f}")
+    if prof: print("   ", {k:(round(v[0],2),v[1]) for k,v in ctx.kernel_times().items()})
+run("cornell-box", 64, False, max_depth=8)
+run("cornell-box", 64, False, max_depth=8)
+run("cornell-box", 64, True, max_depth=8)
+run("cornell-box-guided", 512, False)
+run("cornell-box-guided", 512, True)
+run("cornell-box", 64, True, integrator="lightpath", max_depth=8)
+run("veach-mis", 64, True, resx=1280, resy=720)
