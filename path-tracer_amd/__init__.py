@@ -124,7 +124,7 @@ def load_gpu() -> C.CDLL:
     """Load libptgpu.so. Raises if it was not built — the product path never falls back to a CPU path."""
     global _gpu
     if _gpu is None:
-        path = LIB_DIR / "libptgpu.so"
+        path = Path(os.environ.get("PTGPU_LIB", LIB_DIR / "libptgpu.so"))  # PTGPU_LIB: A/B builds of the same library
         if not path.exists():
             raise PtError(f"{path} is missing: run `make` (or __graft_entry__.build()) first")
         lib = C.CDLL(str(path))

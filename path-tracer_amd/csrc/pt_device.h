@@ -237,15 +237,29 @@ PT_HD float diff_of_products(float a, float b, float c, float d) {  // geom.rs:1
 struct TriHit {
     float t, b0, b1, b2;
 };
+// Per-ray part of ray_triangle_intersection (geom.rs:183-194): dominant axis and shear. It depends on the ray only,
+// so the traversal computes it once per ray instead of once per triangle (three IEEE divisions saved per test;
+// the values, hence the results, are the same bits).
+struct RayShear {
+    int kz;
+    float sx, sy, sz;
+};
+PT_HD RayShear ray_shear(V3 rd) {
+    RayShear r;
+    r.kz = max_axis(absv(rd));
+    const V3 d = permute_kz(rd, r.kz);
+    r.sx = -d.x / d.z;
+    r.sy = -d.y / d.z;
+    r.sz = 1.0f / d.z;
+    return r;
+}
 // ray_triangle_intersection (geom.rs:180-287): PBRT-v4 watertight test, f64 fallback on a zero edge function.
-PT_HD bool ray_triangle(V3 ro, V3 rd, V3 p0, V3 p1, V3 p2, float max_t, TriHit& out) {
+PT_HD bool ray_triangle(V3 ro, const RayShear& rs, V3 p0, V3 p1, V3 p2, float max_t, TriHit& out) {
     V3 p0t = p0 - ro, p1t = p1 - ro, p2t = p2 - ro;
-    int kz = max_axis(absv(rd));
-    V3 d = permute_kz(rd, kz);
-    p0t = permute_kz(p0t, kz);
-    p1t = permute_kz(p1t, kz);
-    p2t = permute_kz(p2t, kz);
-    float sx = -d.x / d.z, sy = -d.y / d.z, sz = 1.0f / d.z;
+    p0t = permute_kz(p0t, rs.kz);
+    p1t = permute_kz(p1t, rs.kz);
+    p2t = permute_kz(p2t, rs.kz);
+    const float sx = rs.sx, sy = rs.sy, sz = rs.sz;
     p0t.x += sx * p0t.z;
     p0t.y += sy * p0t.z;
     p1t.x += sx * p1t.z;
@@ -311,6 +325,7 @@ PT_D Hit bvh_intersect(const SceneDev& sc, V3 o, V3 d, float ray_end_t, uint32_t
     const V3 inv = splat(1.0f) / d;
     const bool nx = inv.x < 0.0f, ny = inv.y < 0.0f, nz = inv.z < 0.0f;
     const float slack = 1.0f + 2.0f * gamma_n(3.0f);
+    const RayShear shear = ray_shear(d);
     uint32_t stack[kBvhStack];
     int sp = 0;
     stack[sp++] = 0;
@@ -344,7 +359,7 @@ PT_D Hit bvh_intersect(const SceneDev& sc, V3 o, V3 d, float ray_end_t, uint32_t
                 const float4 a = sc.tri_v[3 * k], b = sc.tri_v[3 * k + 1], c = sc.tri_v[3 * k + 2];
                 if (COUNT) (*n_tris_tested)++;
                 TriHit th;
-                if (ray_triangle(o, d, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), best.th.t, th)) {
+                if (ray_triangle(o, shear, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), best.th.t, th)) {
                     best.th = th;
                     best.prim = k;
                 }

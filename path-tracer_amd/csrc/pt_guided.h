@@ -254,6 +254,7 @@ PT_HD uint32_t index_in_tile(uint32_t pixel, uint32_t resx) {
 // still spread over all GPUs.
 __global__ __launch_bounds__(kBlock) void k_raygen_guided(SceneDev sc, CameraDev cam, RenderParams rp, GuidedParams gp, PathCols st, RoundCounters* cnt,
                                                           uint32_t n_pairs, uint32_t n_pixels, uint64_t first_pass) {
+    __shared__ BlockAlloc sm_alloc;
     const uint32_t stride = gridDim.x * blockDim.x;
     const uint32_t n_iter = (n_pairs + stride - 1) / stride;
     for (uint32_t it = 0; it < n_iter; it++) {
@@ -266,7 +267,8 @@ __global__ __launch_bounds__(kBlock) void k_raygen_guided(SceneDev sc, CameraDev
             pass = first_pass + g / n_pixels;
             mine = (tile_of_pixel(pixel, cam.resx, gp.tiles_x) + pass) % gp.shard_count == gp.shard_index;
         }
-        const uint32_t slot = wave_alloc(&cnt[0].n_active, mine);
+        uint32_t slot, unused_slot;
+        block_alloc2(sm_alloc, &cnt[0], mine, false, slot, unused_slot);
         if (mine) {
             const uint32_t ix = pixel % cam.resx, iy = pixel / cam.resx;
             Rng rng = rng_init_pixel(ix, iy, pass);
@@ -295,8 +297,11 @@ PT_D void store_vertex(const GuidedParams& gp, uint32_t row, uint32_t pid, V3 p,
 }
 
 // One iteration of PathGuidingIntegrator::random_walk's loop body (mod.rs:139-278).
-__global__ __launch_bounds__(kBlock) void k_shade_guided(SceneDev sc, SdTreeDev tree, RenderParams rp, GuidedParams gp, PathCols in, HitCols hit, PathCols out,
+__global__ __launch_bounds__(kBlock, PT_SHADE_WAVES) void k_shade_guided(SceneDev sc, SdTreeDev tree, RenderParams rp, GuidedParams gp, PathCols in, HitCols hit, PathCols out,
                                                          ShadowCols sh, const RoundCounters* cur, RoundCounters* nxt) {
+    __shared__ BlockAlloc sm_alloc;
+    __shared__ uint32_t sm_count;
+    uint32_t n_shaded = 0, n_skipped = 0;
     const uint32_t n = cur->n_active;
     const uint32_t stride = gridDim.x * blockDim.x;
     const uint32_t n_iter = (n + stride - 1) / stride;
@@ -424,10 +429,10 @@ __global__ __launch_bounds__(kBlock) void k_shade_guided(SceneDev sc, SdTreeDev 
             }
             rp4.w = (rp4.w & 0xffffu) | (nverts << 16);
         }
-        const uint32_t a_slot = wave_alloc(&nxt->n_active, alive);
-        const uint32_t s_slot = wave_alloc(&nxt->n_shadow, want_shadow);
-        wave_count(&nxt->n_segments, shaded);
-        wave_count(&nxt->n_terminal, skipped_shadow);
+        uint32_t a_slot, s_slot;
+        block_alloc2(sm_alloc, nxt, alive, want_shadow, a_slot, s_slot);
+        n_shaded += shaded ? 1u : 0u;
+        n_skipped += skipped_shadow ? 1u : 0u;
         if (alive) {
             out.o_pdf[a_slot] = make_float4(o.x, o.y, o.z, prev_pdf);
             out.d_flags[a_slot] = make_float4(d.x, d.y, d.z, u2f(flags));
@@ -445,6 +450,8 @@ __global__ __launch_bounds__(kBlock) void k_shade_guided(SceneDev sc, SdTreeDev 
             store_spec(sh.q2, sh.q3, s_slot, contrib);
         }
     }
+    block_count_flush(&sm_count, &nxt->n_segments, n_shaded);
+    block_count_flush(&sm_count, &nxt->n_terminal, n_skipped);
 }
 
 // NEE visibility for the guided walk: an unoccluded sample becomes the vertex's li_sample_contribution.

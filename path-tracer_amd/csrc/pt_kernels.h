@@ -8,6 +8,9 @@
 namespace pt {
 
 constexpr int kBlock = 256;
+#ifndef PT_SHADE_WAVES
+#define PT_SHADE_WAVES 2  // minimum waves per SIMD the shade kernels are compiled for (register budget 512 / N)
+#endif
 
 // One atomic per wave: lanes with `want` get consecutive indices from *counter.
 PT_D uint32_t wave_alloc(uint32_t* counter, bool want) {
@@ -20,6 +23,50 @@ PT_D uint32_t wave_alloc(uint32_t* counter, bool want) {
     base = __shfl(base, leader);
     return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
 }
+// Slot allocation for a whole workgroup with ONE global atomic per loop iteration: the (n_active, n_shadow) pair of
+// a RoundCounters is bumped as a single 64-bit word, lanes are ranked with ballots and an LDS add per wave. Every
+// thread of the block must call it (same trip count). Per-wave global atomics on one word saturate near 100 per us
+// (MI355X_MICROARCH.md, "dequeue"), which is what a 4 M-path round would otherwise spend its time on.
+struct BlockAlloc {
+    uint32_t cnt[2];
+    uint32_t base[2];
+};
+PT_D void block_alloc2(BlockAlloc& sm, RoundCounters* rc, bool want_a, bool want_b, uint32_t& slot_a, uint32_t& slot_b) {
+    if (threadIdx.x == 0) sm.cnt[0] = sm.cnt[1] = 0;
+    __syncthreads();
+    const uint32_t lane = __lane_id();
+    const unsigned long long ma = __ballot(want_a), mb = __ballot(want_b);
+    uint32_t wa = 0, wb = 0;
+    if (lane == 0) {
+        if (ma) wa = atomicAdd(&sm.cnt[0], (uint32_t)__popcll(ma));
+        if (mb) wb = atomicAdd(&sm.cnt[1], (uint32_t)__popcll(mb));
+    }
+    wa = __shfl(wa, 0);
+    wb = __shfl(wb, 0);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long add = (unsigned long long)sm.cnt[0] | ((unsigned long long)sm.cnt[1] << 32);
+        unsigned long long old = 0;
+        if (add) old = atomicAdd(reinterpret_cast<unsigned long long*>(&rc->n_active), add);
+        sm.base[0] = (uint32_t)old;
+        sm.base[1] = (uint32_t)(old >> 32);
+    }
+    __syncthreads();
+    const unsigned long long below = (1ull << lane) - 1ull;
+    slot_a = sm.base[0] + wa + (uint32_t)__popcll(ma & below);
+    slot_b = sm.base[1] + wb + (uint32_t)__popcll(mb & below);
+}
+// Sum of a per-thread count over the block, added to *counter once (call after the loop, by every thread).
+PT_D void block_count_flush(uint32_t* sm_word, uint32_t* counter, uint32_t mine) {
+    if (threadIdx.x == 0) *sm_word = 0;
+    __syncthreads();
+    uint32_t v = mine;
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    if (__lane_id() == 0 && v) atomicAdd(sm_word, v);
+    __syncthreads();
+    if (threadIdx.x == 0 && *sm_word) atomicAdd(counter, *sm_word);
+}
+
 PT_D void wave_count(uint32_t* counter, bool want) {
     const unsigned long long mask = __ballot(want);
     if (mask != 0ull && (int)__lane_id() == __ffsll((long long)mask) - 1) atomicAdd(counter, (uint32_t)__popcll(mask));
@@ -158,11 +205,14 @@ __global__ __launch_bounds__(kBlock) void k_occluded_batch(SceneDev sc, const fl
 
 // ------------------------------------------------------------------ shade: `path` integrator
 // One iteration of PathIntegrator::li's loop body after the intersection (path_tracer.rs:69-180).
-__global__ __launch_bounds__(kBlock) void k_shade_path(SceneDev sc, RenderParams rp, PathCols in, HitCols hit, PathCols out, ShadowCols sh,
+__global__ __launch_bounds__(kBlock, PT_SHADE_WAVES) void k_shade_path(SceneDev sc, RenderParams rp, PathCols in, HitCols hit, PathCols out, ShadowCols sh,
                                                        const RoundCounters* cur, RoundCounters* nxt) {
+    __shared__ BlockAlloc sm_alloc;
+    __shared__ uint32_t sm_count;
+    uint32_t n_shaded = 0;
     const uint32_t n = cur->n_active;
     const uint32_t stride = gridDim.x * blockDim.x;
-    const uint32_t n_iter = (n + stride - 1) / stride;  // same trip count for every lane: allocs stay wave-uniform
+    const uint32_t n_iter = (n + stride - 1) / stride;  // same trip count for every thread: allocation is block-uniform
     for (uint32_t it = 0; it < n_iter; it++) {
         const uint32_t i = it * stride + blockIdx.x * blockDim.x + threadIdx.x;
         const bool valid = i < n;
@@ -273,10 +323,10 @@ __global__ __launch_bounds__(kBlock) void k_shade_path(SceneDev sc, RenderParams
         }
         // ---- wave-uniform tail: slot allocation and stores
         const bool want_terminal = valid && !alive && want_shadow;
-        const uint32_t a_slot = wave_alloc(&nxt->n_active, alive);
-        const uint32_t t_slot = wave_alloc(&nxt->n_terminal, want_terminal);
-        const uint32_t s_slot = wave_alloc(&nxt->n_shadow, want_shadow);
-        wave_count(&nxt->n_segments, shaded);
+        uint32_t a_slot, s_slot;
+        block_alloc2(sm_alloc, nxt, alive, want_shadow, a_slot, s_slot);
+        const uint32_t t_slot = wave_alloc(&nxt->n_terminal, want_terminal);  // rare: path ended with a shadow ray pending
+        n_shaded += shaded ? 1u : 0u;
         if (alive) {
             out.o_pdf[a_slot] = make_float4(o.x, o.y, o.z, prev_pdf);
             out.d_flags[a_slot] = make_float4(d.x, d.y, d.z, u2f(flags));
@@ -300,6 +350,7 @@ __global__ __launch_bounds__(kBlock) void k_shade_path(SceneDev sc, RenderParams
         }
         if (do_film && !spec_is_black(L)) film_add(sc, rp.film, rp4.z, L, wl, (flags & FLAG_SECONDARY_TERMINATED) != 0);
     }
+    block_count_flush(&sm_count, &nxt->n_segments, n_shaded);
 }
 
 // ------------------------------------------------------------------ occlude: `path` integrator
@@ -337,6 +388,7 @@ __global__ __launch_bounds__(kBlock) void k_occlude_path(SceneDev sc, RenderPara
 // emission point to the pinhole, start the random walk.
 __global__ __launch_bounds__(kBlock) void k_raygen_light(SceneDev sc, CameraDev cam, RenderParams rp, PathCols st, ShadowCols sh, RoundCounters* cnt,
                                                          uint32_t n_paths, uint32_t n_pixels, uint64_t first_sample, uint64_t sample_step) {
+    __shared__ BlockAlloc sm_alloc;
     const uint32_t stride = gridDim.x * blockDim.x;
     const uint32_t n_iter = (n_paths + stride - 1) / stride;
     for (uint32_t it = 0; it < n_iter; it++) {
@@ -378,8 +430,8 @@ __global__ __launch_bounds__(kBlock) void k_raygen_light(SceneDev sc, CameraDev 
             }
             rp4 = make_uint4((uint32_t)rng.state, (uint32_t)(rng.state >> 32), pixel, (uint32_t)si);
         }
-        const uint32_t a_slot = wave_alloc(&cnt[0].n_active, alive);
-        const uint32_t s_slot = wave_alloc(&cnt[0].n_shadow, want_splat);
+        uint32_t a_slot, s_slot;
+        block_alloc2(sm_alloc, &cnt[0], alive, want_splat, a_slot, s_slot);
         if (alive) {
             st.o_pdf[a_slot] = make_float4(o.x, o.y, o.z, 0.0f);
             st.d_flags[a_slot] = make_float4(d.x, d.y, d.z, u2f(0u));
@@ -399,8 +451,11 @@ __global__ __launch_bounds__(kBlock) void k_raygen_light(SceneDev sc, CameraDev 
 
 // LightPathIntegrator::random_walk loop body (light_path_tracer.rs:74-118). The depth counter counts loop
 // iterations (a pass-through surface burns one, unlike `path`).
-__global__ __launch_bounds__(kBlock) void k_shade_light(SceneDev sc, CameraDev cam, RenderParams rp, PathCols in, HitCols hit, PathCols out, ShadowCols sh,
+__global__ __launch_bounds__(kBlock, PT_SHADE_WAVES) void k_shade_light(SceneDev sc, CameraDev cam, RenderParams rp, PathCols in, HitCols hit, PathCols out, ShadowCols sh,
                                                         const RoundCounters* cur, RoundCounters* nxt) {
+    __shared__ BlockAlloc sm_alloc;
+    __shared__ uint32_t sm_count;
+    uint32_t n_shaded = 0;
     const uint32_t n = cur->n_active;
     const uint32_t stride = gridDim.x * blockDim.x;
     const uint32_t n_iter = (n + stride - 1) / stride;
@@ -463,9 +518,9 @@ __global__ __launch_bounds__(kBlock) void k_shade_light(SceneDev sc, CameraDev c
             flags = (flags & ~FLAG_DEPTH_MASK) | (depth & FLAG_DEPTH_MASK);
             alive = alive && depth < rp.max_depth;
         }
-        const uint32_t a_slot = wave_alloc(&nxt->n_active, alive);
-        const uint32_t s_slot = wave_alloc(&nxt->n_shadow, want_splat);
-        wave_count(&nxt->n_segments, shaded);
+        uint32_t a_slot, s_slot;
+        block_alloc2(sm_alloc, nxt, alive, want_splat, a_slot, s_slot);
+        n_shaded += shaded ? 1u : 0u;
         if (alive) {
             out.o_pdf[a_slot] = make_float4(o.x, o.y, o.z, 0.0f);
             out.d_flags[a_slot] = make_float4(d.x, d.y, d.z, u2f(flags));
@@ -480,7 +535,7 @@ __global__ __launch_bounds__(kBlock) void k_shade_light(SceneDev sc, CameraDev c
             r[3 * (size_t)s_slot + 1] = rgb[1];
             r[3 * (size_t)s_slot + 2] = rgb[2];
         }
-    }
+    }    block_count_flush(&sm_count, &nxt->n_segments, n_shaded);
 }
 
 // Camera-connection visibility + Film::add_splat (camera.rs:161-166) with f64 atomics.
