@@ -4,7 +4,7 @@ CXX ?= g++
 PKG = path-tracer_amd
 LIB = $(PKG)/lib
 # -ffp-contract=off: hit records must be bit-identical to the CPU restatement; fma only where written.
-HIPFLAGS = -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -munsafe-fp-atomics -fPIC -Wall -Wno-unused-function
+HIPFLAGS = -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -munsafe-fp-atomics -fPIC -pthread -Wall -Wno-unused-function
 CSRC = $(PKG)/csrc
 GPU_DEPS = $(wildcard $(CSRC)/*.h $(CSRC)/*.inc) include/ptgpu.h
 

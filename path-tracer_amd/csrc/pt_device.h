@@ -149,8 +149,9 @@ PT_D float visible_pdf(float lambda) {  // mod.rs:157-159
     float c = coshf(0.0072f * (lambda - 538.0f));
     return 0.0039398042f / (c * c);
 }
-struct Lambdas {
+struct Lambdas {  // SampledWavelengths (mod.rs:15-18) before any terminate_secondary
     float l[NSW];
+    float pdf[NSW];
 };
 PT_D Lambdas sample_visible(float u1d) {  // mod.rs:103-117
     Lambdas r;
@@ -159,6 +160,25 @@ PT_D Lambdas sample_visible(float u1d) {  // mod.rs:103-117
         float u = u1d + (float)i / (float)NSW;
         if (u >= 1.0f) u -= 1.0f;
         r.l[i] = sample_visible_lambda(u);
+        r.pdf[i] = visible_pdf(r.l[i]);
+    }
+    return r;
+}
+// The wavelength sample of a path is one of a few hundred table values (see ptgpu.hip, wavelength tables), so the
+// 8 wavelengths and pdfs are evaluated once per table entry (k_build_lambda_table) and every stage reads the 64-byte
+// row instead of redoing 8 atanh + 8 cosh per segment.
+PT_D Lambdas load_lambdas(const float4* __restrict__ tab, uint32_t idx, bool with_pdf) {
+    Lambdas r;
+    const float4 a = tab[4 * (size_t)idx], b = tab[4 * (size_t)idx + 1];
+    r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
+    r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
+    if (with_pdf) {
+        const float4 c = tab[4 * (size_t)idx + 2], d = tab[4 * (size_t)idx + 3];
+        r.pdf[0] = c.x; r.pdf[1] = c.y; r.pdf[2] = c.z; r.pdf[3] = c.w;
+        r.pdf[4] = d.x; r.pdf[5] = d.y; r.pdf[6] = d.z; r.pdf[7] = d.w;
+    } else {
+#pragma unroll
+        for (int i = 0; i < NSW; i++) r.pdf[i] = 0.0f;
     }
     return r;
 }
@@ -190,7 +210,7 @@ PT_D void spec_to_rgb(const Spec& l, const Lambdas& wl, bool secondary_terminate
     double X = 0.0, Y = 0.0, Z = 0.0;
 #pragma unroll
     for (int i = 0; i < NSW; i++) {
-        float pdf = visible_pdf(wl.l[i]);
+        float pdf = wl.pdf[i];
         if (secondary_terminated) pdf = (i == 0) ? pdf / (float)NSW : 0.0f;
         if (pdf != 0.0f) {
             const double* c = cie_xyz + 3 * lambda_index(wl.l[i]);

@@ -151,21 +151,29 @@ PT_D bool guider_sample(const SdTreeDev& t, const Bsdf& bsdf, const Frame& fr, V
     }
     V3 lo, hi;
     const uint4 leaf = t.leaf_info[stree_leaf(t, p, lo, hi)];
-    if (rng_f32(rng) < 0.5f) {
-        const V2 sq = dtree_sample(t, leaf, rng);
-        const V3 wi = square_to_dir(sq);
-        const float bp = bsdf_pdf(bsdf, fr, wo, wi) * 0.5f;
+    // Both branches need the tree's pdf at the chosen direction; the quadtree descent is hoisted out of the branch
+    // so a wave walks it once with all lanes instead of twice with half of them. Values are unchanged.
+    const bool use_tree = rng_f32(rng) < 0.5f;
+    V2 sq;
+    if (use_tree) {
+        sq = dtree_sample(t, leaf, rng);
+        s.wi = square_to_dir(sq);
+    } else {
+        const float u1d = rng_f32(rng), ua = rng_f32(rng), ub = rng_f32(rng);
+        if (!bsdf_sample(bsdf, fr, ng, wo, u1d, ua, ub, true, s)) return false;
+        sq = dir_to_square(s.wi);
+    }
+    const float tree_pdf = dtree_pdf(t, leaf, sq);
+    if (use_tree) {
+        const float bp = bsdf_pdf(bsdf, fr, wo, s.wi) * 0.5f;
         if (bp == 0.0f) return false;  // the tree proposed a direction the BSDF cannot produce: the walk ends here
-        s.pdf = bp + dtree_pdf(t, leaf, sq) * 0.5f;
-        s.f = bsdf_eval(bsdf, fr, ng, wo, wi, true);
-        s.wi = wi;
+        s.pdf = bp + tree_pdf * 0.5f;
+        s.f = bsdf_eval(bsdf, fr, ng, wo, s.wi, true);
         s.specular = false;
         s.terminate_secondary = false;
-        return true;
+    } else {
+        s.pdf = 0.5f * s.pdf + 0.5f * tree_pdf;
     }
-    const float u1d = rng_f32(rng), ua = rng_f32(rng), ub = rng_f32(rng);
-    if (!bsdf_sample(bsdf, fr, ng, wo, u1d, ua, ub, true, s)) return false;
-    s.pdf = 0.5f * s.pdf + 0.5f * dtree_pdf(t, leaf, dir_to_square(s.wi));
     return true;
 }
 
@@ -335,7 +343,7 @@ __global__ __launch_bounds__(kBlock, PT_SHADE_WAVES) void k_shade_guided(SceneDe
             } else {
                 const float4 tb = hit.tb[i];
                 beta = load_spec(in.beta0, in.beta1, i);
-                const Lambdas wl = sample_visible(rp.lambda_u[rp4.w & 0xffffu]);
+                const Lambdas wl = load_lambdas(rp.lambda_tab, rp4.w & 0xffffu, false);
                 const Surface sf = make_surface(sc, prim, tb.y, tb.z, tb.w);
                 const int material = sc.mesh_info[sf.tri.mesh].material;
                 uint32_t depth = flags & FLAG_DEPTH_MASK;
@@ -490,7 +498,7 @@ __global__ __launch_bounds__(kBlock) void k_guide_record(SceneDev sc, SdTreeDev 
             l = l + load_spec(gp.vtx.e0, gp.vtx.e1, k);
         }
         if (gp.write_film) {
-            const Lambdas wl = sample_visible(rp.lambda_u[rp4.w & 0xffffu]);
+            const Lambdas wl = load_lambdas(rp.lambda_tab, rp4.w & 0xffffu, true);
             film_add(sc, rp.film, rp4.z, l, wl, (flags & FLAG_SECONDARY_TERMINATED) != 0);
         }
     }

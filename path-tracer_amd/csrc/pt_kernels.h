@@ -115,9 +115,19 @@ struct RenderParams {
     int mode;
     uint32_t capacity;       // slots per state set
     uint32_t resx;           // image width (pixel index = x + y*resx)
-    const float* lambda_u;   // wavelength-sample table (see ptgpu.hip: wavelength tables)
+    const float4* lambda_tab;  // per wavelength-table entry: 8 lambdas + 8 pdfs (see ptgpu.hip: wavelength tables)
     double* film;            // resx*resy*3
 };
+
+__global__ __launch_bounds__(kBlock) void k_build_lambda_table(const float* u, float4* tab, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const Lambdas w = sample_visible(u[i]);
+    tab[4 * (size_t)i + 0] = make_float4(w.l[0], w.l[1], w.l[2], w.l[3]);
+    tab[4 * (size_t)i + 1] = make_float4(w.l[4], w.l[5], w.l[6], w.l[7]);
+    tab[4 * (size_t)i + 2] = make_float4(w.pdf[0], w.pdf[1], w.pdf[2], w.pdf[3]);
+    tab[4 * (size_t)i + 3] = make_float4(w.pdf[4], w.pdf[5], w.pdf[6], w.pdf[7]);
+}
 
 // ------------------------------------------------------------------ ray generation
 // Sampler::init_pixel + wavelength_sample + Camera::sample_we (path_tracer.rs:40-43).
@@ -232,7 +242,7 @@ __global__ __launch_bounds__(kBlock, PT_SHADE_WAVES) void k_shade_path(SceneDev 
             flags = f2u(d4.w);
             rp4 = in.rng_px[i];
             L = load_spec(in.L0, in.L1, i);
-            wl = sample_visible(rp.lambda_u[rp4.w]);
+            wl = load_lambdas(rp.lambda_tab, rp4.w, true);
             const uint32_t prim = hit.prim[i];
             if (prim == kNoHit) {
                 do_film = true;  // eval_envmap == ZERO without an envmap (scene.rs:301-306)
@@ -372,7 +382,7 @@ __global__ __launch_bounds__(kBlock) void k_occlude_path(SceneDev sc, RenderPara
             if (!spec_is_black(L)) {
                 const uint4 rp4 = st.rng_px[slot];
                 const uint32_t flags = f2u(st.d_flags[slot].w);
-                const Lambdas wl = sample_visible(rp.lambda_u[rp4.w]);
+                const Lambdas wl = load_lambdas(rp.lambda_tab, rp4.w, true);
                 film_add(sc, rp.film, rp4.z, L, wl, (flags & FLAG_SECONDARY_TERMINATED) != 0);
             }
         } else if (!occ) {
@@ -404,7 +414,7 @@ __global__ __launch_bounds__(kBlock) void k_raygen_light(SceneDev sc, CameraDev 
             const uint64_t si = first_sample + (uint64_t)slot * sample_step;
             const uint32_t ix = pixel % cam.resx, iy = pixel / cam.resx;
             Rng rng = rng_init_pixel(ix, iy, si);
-            const Lambdas wl = sample_visible(rp.lambda_u[(uint32_t)si]);
+            const Lambdas wl = load_lambdas(rp.lambda_tab, (uint32_t)si, true);
             const float u1d = rng_f32(rng), u00 = rng_f32(rng), u01 = rng_f32(rng), u10 = rng_f32(rng), u11 = rng_f32(rng);
             Tri lt;
             float pmf;
@@ -475,7 +485,7 @@ __global__ __launch_bounds__(kBlock, PT_SHADE_WAVES) void k_shade_light(SceneDev
             rp4 = in.rng_px[i];
             beta = load_spec(in.beta0, in.beta1, i);
             const float4 tb = hit.tb[i];
-            const Lambdas wl = sample_visible(rp.lambda_u[rp4.w]);
+            const Lambdas wl = load_lambdas(rp.lambda_tab, rp4.w, true);
             const Surface sf = make_surface(sc, hit.prim[i], tb.y, tb.z, tb.w);
             const int material = sc.mesh_info[sf.tri.mesh].material;
             uint32_t depth = (flags & FLAG_DEPTH_MASK) + 1;  // iterations consumed including this one

@@ -102,6 +102,7 @@ struct ptgpu_ctx {
     DevBuf<RoundCounters> d_counters;
     DevBuf<double> d_film;
     DevBuf<float> d_lambda_u;
+    DevBuf<float4> d_lambda_tab;  // 4 float4 per table entry: lambdas, pdfs
     std::vector<RoundCounters> h_counters;
     bool profiling = false;
     // HIP-event pool: each launch records a start/stop pair on the library's stream without waiting; the pairs are
@@ -507,6 +508,15 @@ void launch_extend(ptgpu_ctx* c, int grid, const PathCols& A, const HitCols& H, 
     else hipLaunchKernelGGL(k_extend<false>, dim3(grid), dim3(kBlock), 0, c->stream, c->scene, A, H, cnt, c->d_census.p);
 }
 
+int upload_lambda_table(ptgpu_ctx* c, const std::vector<float>& u) {
+    HIP_TRY(c->d_lambda_u.upload(u, c->stream));
+    HIP_TRY(c->d_lambda_tab.alloc(4 * u.size()));
+    const uint32_t n = (uint32_t)u.size();
+    hipLaunchKernelGGL(k_build_lambda_table, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, c->d_lambda_u.p, c->d_lambda_tab.p, n);
+    HIP_TRY(hipGetLastError());
+    return PTGPU_OK;
+}
+
 uint32_t pick_capacity(const ptgpu_ctx* c, uint64_t total_paths) {
     uint64_t cap = c->batch_paths ? c->batch_paths : (1ull << 22);
     const uint64_t npix = (uint64_t)c->camera.resx * c->camera.resy;
@@ -598,13 +608,14 @@ int render_path_like(ptgpu_ctx* c, const ptgpu_integrator_desc* integ, uint32_t 
     if (my_samples == 0 || integ->max_depth == 0) return PTGPU_OK;
     int rc = ensure_workspace(c, pick_capacity(c, my_samples * npix));
     if (rc != PTGPU_OK) return rc;
-    HIP_TRY(c->d_lambda_u.upload(golden_iterates(spp), c->stream));
+    rc = upload_lambda_table(c, golden_iterates(spp));
+    if (rc != PTGPU_OK) return rc;
     RenderParams rp;
     rp.max_depth = integ->max_depth > 0xffffu ? 0xffffu : integ->max_depth;
     rp.mode = integ->mode;
     rp.capacity = c->capacity;
     rp.resx = c->camera.resx;
-    rp.lambda_u = c->d_lambda_u.p;
+    rp.lambda_tab = c->d_lambda_tab.p;
     rp.film = c->d_film.p;
     const uint64_t passes_per_batch = c->capacity / npix;
     for (uint64_t done = 0; done < my_samples; done += passes_per_batch) {

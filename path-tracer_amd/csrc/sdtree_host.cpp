@@ -1,10 +1,45 @@
 // sdtree_host.cpp — see sdtree_host.h. Host code only.
 #include "sdtree_host.h"
 
+#include <algorithm>
+#include <atomic>
+#include <cstdlib>
+#include <thread>
 #include <utility>
 
 namespace pt {
 namespace {
+
+// The per-leaf work between waves (sum rebuild, copy into the sampling tree, directional refinement, flattening) is
+// independent per spatial leaf; with ~10^4 leaves and ~10^6 quadtree nodes it is spread over the host cores.
+int host_threads() {
+    static const int n = [] {
+        if (const char* e = getenv("PTGPU_HOST_THREADS")) return std::max(1, atoi(e));
+        const unsigned hc = std::thread::hardware_concurrency();
+        return (int)std::max(1u, std::min(16u, hc ? hc : 1u));
+    }();
+    return n;
+}
+template <class F>
+void parallel_for(size_t n, size_t grain, F f) {
+    const int nt = (int)std::min<size_t>(host_threads(), (n + grain - 1) / std::max<size_t>(1, grain));
+    if (nt <= 1) {
+        for (size_t i = 0; i < n; i++) f(i);
+        return;
+    }
+    std::atomic<size_t> next{0};
+    std::vector<std::thread> pool;
+    for (int t = 0; t < nt; t++)
+        pool.emplace_back([&] {
+            for (;;) {
+                const size_t b = next.fetch_add(grain);
+                if (b >= n) return;
+                const size_t e = std::min(n, b + grain);
+                for (size_t i = b; i < e; i++) f(i);
+            }
+        });
+    for (auto& t : pool) t.join();
+}
 
 // DTree::build (dtree.rs:185-198): interior children take the sum of their subtree, bottom-up.
 float rebuild_sums(HostDTree& t, uint16_t ni) {
@@ -119,16 +154,19 @@ bool HostSdTree::new_iteration(float directional_threshold, float spatial_thresh
         nodes.push_back(std::move(b));
     }
     // STreeNode::subdivide_dtree for every leaf (stree.rs:49-53,255-260)
-    for (HostSNode& n : nodes) {
-        if (n.left != 0) continue;
+    std::atomic<bool> ok{true};
+    parallel_for(nodes.size(), 16, [&](size_t i) {
+        HostSNode& n = nodes[i];
+        if (n.left != 0) return;
         rebuild_sums(n.collector, 0);
         n.sampler.weight = n.collector.weight;  // emit_into (dtree.rs:325-328)
         n.sampler.nodes = n.collector.nodes;
         n.sampler.free_slots = n.collector.free_slots;
-        if (!refine_directional(n.collector, directional_threshold)) {
-            if (err) *err = "a directional quadtree needs more than 65535 nodes (u16 child links)";
-            return false;
-        }
+        if (!refine_directional(n.collector, directional_threshold)) ok = false;
+    });
+    if (!ok) {
+        if (err) *err = "a directional quadtree needs more than 65535 nodes (u16 child links)";
+        return false;
     }
     return true;
 }
@@ -136,10 +174,9 @@ bool HostSdTree::new_iteration(float directional_threshold, float spatial_thresh
 void HostSdTree::flatten(SdTreeFlat& out) const {
     out.snodes.assign(nodes.size(), make_uint4(0, 0, 0, 0));
     out.leaf_info.clear();
-    out.s_rad.clear();
-    out.s_child.clear();
-    out.c_child.clear();
     out.leaf_snode.clear();
+    // pass 1 (serial, cheap): leaf numbering and arena offsets
+    size_t s_total = 0, c_total = 0;
     for (size_t i = 0; i < nodes.size(); i++) {
         const HostSNode& n = nodes[i];
         if (n.left != 0) {
@@ -150,26 +187,36 @@ void HostSdTree::flatten(SdTreeFlat& out) const {
         out.snodes[i] = make_uint4(0, 0, n.axis, leaf);
         // DTree::mean() == 0 (dtree.rs:71-77) decides between uniform and tree sampling
         const float mean = n.sampler.weight == 0.0f ? 0.0f : n.sampler.nodes[0].sum() / (kFourPi * n.sampler.weight);
-        out.leaf_info.push_back(make_uint4((uint32_t)out.s_rad.size(), (uint32_t)out.c_child.size(), mean == 0.0f ? 1u : 0u, 0u));
+        out.leaf_info.push_back(make_uint4((uint32_t)s_total, (uint32_t)c_total, mean == 0.0f ? 1u : 0u, 0u));
         out.leaf_snode.push_back((uint32_t)i);
-        for (const HostDNode& d : n.sampler.nodes) {
-            out.s_rad.push_back(make_float4(d.rad[0], d.rad[1], d.rad[2], d.rad[3]));
-            out.s_child.push_back(pack_children(d));
-        }
-        for (const HostDNode& d : n.collector.nodes) out.c_child.push_back(pack_children(d));
+        s_total += n.sampler.nodes.size();
+        c_total += n.collector.nodes.size();
     }
-    out.n_collector_nodes = (uint32_t)out.c_child.size();
+    out.s_rad.resize(s_total);
+    out.s_child.resize(s_total);
+    out.c_child.resize(c_total);
+    out.n_collector_nodes = (uint32_t)c_total;
+    // pass 2 (parallel): copy the quadtrees into the arenas
+    parallel_for(out.leaf_snode.size(), 16, [&](size_t leaf) {
+        const HostSNode& n = nodes[out.leaf_snode[leaf]];
+        size_t so = out.leaf_info[leaf].x, co = out.leaf_info[leaf].y;
+        for (const HostDNode& d : n.sampler.nodes) {
+            out.s_rad[so] = make_float4(d.rad[0], d.rad[1], d.rad[2], d.rad[3]);
+            out.s_child[so++] = pack_children(d);
+        }
+        for (const HostDNode& d : n.collector.nodes) out.c_child[co++] = pack_children(d);
+    });
 }
 
 void HostSdTree::load_collector_stats(const SdTreeFlat& layout, const float* stats) {
     const float* weights = stats + 4 * (size_t)layout.n_collector_nodes;
-    for (size_t leaf = 0; leaf < layout.leaf_snode.size(); leaf++) {
+    parallel_for(layout.leaf_snode.size(), 16, [&](size_t leaf) {
         HostSNode& n = nodes[layout.leaf_snode[leaf]];
         const float* r = stats + 4 * (size_t)layout.leaf_info[leaf].y;
         for (size_t k = 0; k < n.collector.nodes.size(); k++)
             for (int c = 0; c < 4; c++) n.collector.nodes[k].rad[c] = r[4 * k + c];
         n.collector.weight = weights[leaf];
-    }
+    });
 }
 
 uint64_t HostSdTree::total_sampler_nodes() const {
