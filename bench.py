@@ -36,13 +36,6 @@ WORKLOADS = {
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 
 
-class DeviceArray:
-    """Raw device pointer -> torch tensor (zero copy) through __cuda_array_interface__."""
-
-    def __init__(self, ptr, count):
-        self.__cuda_array_interface__ = {"shape": (count,), "typestr": "<f4", "data": (ptr, False), "version": 2}
-
-
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -58,6 +51,7 @@ def main() -> int:
     import torch.distributed as dist
 
     import path_tracer_amd as pt
+    from path_tracer_amd import multi_gpu as mg
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -82,27 +76,12 @@ def main() -> int:
     guided = integ.kind == pt.INTEGRATOR_GUIDED
     film_dev = torch.zeros((resy, resx, 3), dtype=torch.float64, device=dev) if world > 1 else None
 
+    wrap = mg.device_stats_tensor(torch, dev)
+
     def step():
         """One render of the whole workload; returns (film sums on rank 0, film_scale, stats of this rank)."""
-        if guided:
-            n_waves = ctx.guided_begin(integ, spp, rank, world)
-            for w in range(n_waves):
-                ctx.guided_wave(w)
-                if world > 1 and w + 1 < n_waves:
-                    ptr, count = ctx.guided_stats()
-                    t = torch.as_tensor(DeviceArray(ptr, count), device=dev)
-                    dist.all_reduce(t, op=dist.ReduceOp.SUM)   # RCCL over xGMI, in place on the library's buffer
-                    torch.cuda.synchronize(dev)
-            film, scale, st = ctx.guided_end()
-        else:
-            film, scale, st = ctx.render(integ, spp, rank, world)
-        if world > 1:
-            film_dev.copy_(torch.from_numpy(film))
-            dist.reduce(film_dev, dst=0, op=dist.ReduceOp.SUM)
-            torch.cuda.synchronize(dev)
-            if rank == 0:
-                film = film_dev.cpu().numpy()
-        return film, scale, st
+        return mg.render_sharded(ctx, integ, spp, rank, world, guided, dist=dist, wrap_stats=wrap, film_buf=film_dev,
+                                 sync=lambda: torch.cuda.synchronize(dev))
 
     def fence():
         if world > 1:

@@ -1,0 +1,158 @@
+"""world_size-2 rehearsal of the multi-GPU driver (path-tracer_amd/multi_gpu.py) on CPU with the gloo backend.
+
+What runs here is the SAME driver function bench.py uses with RCCL; the renderer behind it is a stand-in:
+  * path / lightpath: the oracle rendering its sample-index shard — the reduced film must equal the unsharded render;
+  * guided: a stub context that deals (pass, tile) pairs by the library's rule and deposits one unit per pair into a
+    statistics buffer — after the per-wave all-reduce every rank must see every pair exactly once.
+No GPU and no libptgpu compute is involved (the C ABI has no CPU path by design).
+"""
+import os
+import socket
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+REPO = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(REPO))
+sys.path.insert(0, str(REPO / "tests"))
+
+WORLD = 2
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+class OracleShardContext:
+    """render() of path_tracer_amd.Context, served by the oracle (same shard semantics as ptgpu_render_shard)."""
+
+    def __init__(self, scene, cam):
+        import oracle_bind as ob
+        self.o = ob.OracleScene(scene)
+        self.cam = cam
+
+    def render(self, integ, spp, rank, world):
+        return self.o.render(self.cam, integ, spp, shard_index=rank, shard_count=world, n_threads=2)
+
+
+class StubGuidedContext:
+    """guided_{begin,wave,stats,end} with the library's wave schedule and (pass, tile) ownership rule."""
+
+    def __init__(self, n_tiles, wave_passes):
+        self.n_tiles, self.wave_passes = n_tiles, wave_passes
+        self.calls = []
+
+    def guided_begin(self, integ, spp, rank, world):
+        self.rank, self.world = rank, world
+        self.seen_after_reduce = []
+        return len(self.wave_passes)
+
+    def guided_wave(self, w):
+        from path_tracer_amd import multi_gpu as mg
+        if w > 0:
+            self.seen_after_reduce.append(self.stats.clone())  # what the host refinement of wave w-1 would read
+        self.stats = torch.zeros(self.wave_passes[w] * self.n_tiles, dtype=torch.float32)
+        for k in range(self.wave_passes[w]):
+            for t in range(self.n_tiles):
+                if mg.shard_of_pair(t, k, self.world) == self.rank:
+                    self.stats[k * self.n_tiles + t] += 1.0
+        self.calls.append(("wave", w))
+
+    def guided_stats(self):
+        self.calls.append(("stats",))
+        return self.stats, self.stats.numel()
+
+    def guided_end(self):
+        film = np.full((4, 4, 3), float(self.stats.sum()), dtype=np.float64)  # last wave: this rank's pairs only
+        return film, 1.0, {"samples": int(self.stats.sum())}
+
+
+def _worker(rank, port, q):
+    import torch.distributed as dist
+
+    import path_tracer_amd as pt
+    import scenes_util as su
+    from path_tracer_amd import multi_gpu as mg
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(WORLD))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    try:
+        out = {}
+        # ---- path and lightpath: film of the shards == film of the whole
+        sc = su.furnace_scene("plain")
+        cam = pt.make_camera(su.IDENTITY, 39.5, 12, 8)
+        ctx = OracleShardContext(sc, cam)
+        for name, kind, spp in (("path", pt.INTEGRATOR_PATH, 7), ("lightpath", pt.INTEGRATOR_LIGHTPATH, 9)):
+            integ = pt.make_integrator(kind, 6, pt.MODE_MIS)
+            buf = torch.zeros((8, 12, 3), dtype=torch.float64)
+            film, scale, st = mg.render_sharded(ctx, integ, spp, rank, WORLD, False, dist=dist, film_buf=buf)
+            n = torch.tensor([st["samples"]], dtype=torch.int64)
+            dist.all_reduce(n)
+            if rank == 0:
+                whole, wscale, wst = ctx.o.render(cam, integ, spp, n_threads=2)
+                out[name] = (film, scale, int(n.item()), whole, wscale, wst["samples"])
+        # ---- guided: per-wave all-reduce sees each (pass, tile) pair once
+        g = StubGuidedContext(n_tiles=13, wave_passes=[1, 2, 4, 8])
+        buf = torch.zeros((4, 4, 3), dtype=torch.float64)
+        film, _, _ = mg.render_sharded(g, None, 15, rank, WORLD, True, dist=dist, wrap_stats=lambda p, c: p, film_buf=buf)
+        out["guided"] = ([s.numpy() for s in g.seen_after_reduce], g.calls, film)
+        q.put((rank, out))
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.fixture(scope="module")
+def two_ranks():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, port, q)) for r in range(WORLD)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    return results
+
+
+@pytest.mark.parametrize("name", ["path", "lightpath"])
+def test_sample_shards_reduce_to_the_unsharded_film(two_ranks, name):
+    film, scale, n, whole, wscale, wn = two_ranks[0][name]
+    assert n == wn and scale == wscale
+    assert whole.sum() > 0
+    # identical samples, only the f64 summation order differs
+    np.testing.assert_allclose(film, whole, rtol=1e-12, atol=1e-12)
+
+
+def test_guided_pairs_are_dealt_once_and_reduced_every_wave_but_the_last(two_ranks):
+    for rank in range(WORLD):
+        seen, calls, film = two_ranks[rank]["guided"]
+        assert len(seen) == 3
+        for s in seen:
+            assert np.array_equal(s, np.ones_like(s))      # after the all-reduce: every pair exactly once
+        assert calls == [("wave", 0), ("stats",), ("wave", 1), ("stats",), ("wave", 2), ("stats",), ("wave", 3)]
+    # film reduce: rank 0 holds the pairs of the last wave from both ranks (8 passes x 13 tiles)
+    assert np.all(two_ranks[0]["guided"][2] == 8 * 13)
+
+
+def test_shard_rules_balance():
+    from path_tracer_amd import multi_gpu as mg
+    for world in (1, 2, 4, 8):
+        for spp in (1, 7, 512):
+            got = sorted(i for r in range(world) for i in mg.samples_of_shard(spp, r, world))
+            assert got == list(range(spp))
+        for passes in (1, 2, 4, 8):
+            load = [0] * world
+            for k in range(passes):
+                for t in range(1024):
+                    load[mg.shard_of_pair(t, k, world)] += 1
+            assert max(load) - min(load) <= passes   # a one-pass wave still feeds every GPU
