@@ -222,16 +222,15 @@ PT_D void dtree_record_box(const SdTreeDev& t, uint32_t leaf_id, uint4 leaf, V2 
     }
 }
 
-// STree::record with the stochastic spatial filter (stree.rs:102-116,186-201).
-PT_D void stree_record(const SdTreeDev& t, V3 p, V3 wi, float radiance, Rng& rng) {
-    if (!isfinite(radiance) || radiance == 0.0f) return;
+// STree::record with the stochastic spatial filter (stree.rs:102-116,186-201); the caller has checked that
+// `radiance` is finite and non-zero and has drawn the three jitter numbers.
+PT_D void stree_record_jittered(const SdTreeDev& t, V3 p, V3 wi, float radiance, float u0, float u1, float u2) {
     const V2 p2 = dir_to_square(wi);
     V3 lo, hi;
     (void)stree_leaf(t, p, lo, hi);
     const V3 ext = hi - lo;
     const V3 jlo = p - ext / 2.0f;  // Bounds3::around(p, extent)
     const V3 jhi = p + ext / 2.0f;
-    const float u0 = rng_f32(rng), u1 = rng_f32(rng), u2 = rng_f32(rng);
     const V3 q = clamp3(jlo + mk3(u0, u1, u2) * (jhi - jlo), t.blo, t.bhi);
     const uint32_t leaf_id = stree_leaf(t, q, lo, hi);
     dtree_record_box(t, leaf_id, t.leaf_info[leaf_id], p2, radiance);
@@ -480,26 +479,93 @@ __global__ __launch_bounds__(kBlock) void k_occlude_guided(SceneDev sc, GuidedPa
 }
 
 // Back-to-front pass over each finished path (mod.rs:106-116): what arrives at a vertex from further along the path
-// is recorded into the SD-tree, then folded through the vertex. One lane per path; row v of all paths is contiguous.
-__global__ __launch_bounds__(kBlock) void k_guide_record(SceneDev sc, SdTreeDev tree, RenderParams rp, GuidedParams gp, uint32_t n_paths) {
-    const uint32_t stride = gridDim.x * blockDim.x;
-    for (uint32_t pid = blockIdx.x * blockDim.x + threadIdx.x; pid < n_paths; pid += stride) {
-        const uint4 rp4 = gp.tail.rng_px[pid];
-        const uint32_t flags = gp.tail.nverts_flags[pid];
+// is recorded into the SD-tree, then folded through the vertex. Two kernels:
+//   k_guide_scan  — one lane per path walks its vertices back to front (row v of all paths is contiguous), draws the
+//                   three jitter numbers of every record that will happen (STree::record draws only for a finite,
+//                   non-zero radiance, so the PCG sequence is the reference's) and appends {p, radiance, wi, jitter}
+//                   to the record queue; it also adds the finished path to the film.
+//   k_guide_splat — one lane per queued record does the tree work (two spatial descents, the quadtree box splat).
+// Splitting keeps the divergent, latency-bound tree work on dense lanes. The queue needs no global atomics: chunk c
+// (path ids [256c, 256c+256)) owns entries [c*256*n_rows, ...) and its length lands in count[c].
+struct RecordQueue {
+    float4* q0;       // p.xyz, radiance
+    float4* q1;       // wi.xyz, u0
+    float2* q2;       // u1, u2
+    uint32_t* count;  // records per chunk
+};
+
+__global__ __launch_bounds__(kBlock) void k_guide_scan(SceneDev sc, RenderParams rp, GuidedParams gp, RecordQueue rq, uint32_t n_paths) {
+    __shared__ uint32_t sm_n;
+    const uint32_t n_chunks = (n_paths + kBlock - 1) / kBlock;
+    const uint32_t lane = __lane_id();
+    for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+        if (threadIdx.x == 0) sm_n = 0;
+        __syncthreads();
+        const uint32_t pid = chunk * kBlock + threadIdx.x;
+        const bool valid = pid < n_paths;
+        uint4 rp4 = make_uint4(0, 0, 0, 0);
+        uint32_t flags = 0;
+        if (valid) {
+            rp4 = gp.tail.rng_px[pid];
+            flags = gp.tail.nverts_flags[pid];
+        }
         const uint32_t nverts = rp4.w >> 16;
+        uint32_t wave_rows = nverts;
+        for (int off = 32; off > 0; off >>= 1) wave_rows = max(wave_rows, (uint32_t)__shfl_xor((int)wave_rows, off));
         Rng rng{(uint64_t)rp4.x | ((uint64_t)rp4.y << 32), rng_inc_for_pixel(rp4.z % rp.resx, rp4.z / rp.resx)};
         Spec l = spec_splat(0.0f);
-        for (uint32_t v = nverts; v-- > 0;) {
-            const size_t k = (size_t)v * gp.row_stride + pid;
-            const float4 pp = gp.vtx.p_pdf[k], wi = gp.vtx.wi[k];
-            stree_record(tree, mk3(pp.x, pp.y, pp.z), mk3(wi.x, wi.y, wi.z), spec_average(l) / pp.w, rng);
-            l = l * load_spec(gp.vtx.f0, gp.vtx.f1, k);
-            l = l + load_spec(gp.vtx.li0, gp.vtx.li1, k);
-            l = l + load_spec(gp.vtx.e0, gp.vtx.e1, k);
+        const size_t base = (size_t)chunk * kBlock * gp.n_rows;
+        for (uint32_t v = wave_rows; v-- > 0;) {
+            bool want = false;
+            float4 pp = make_float4(0, 0, 0, 0), wi = make_float4(0, 0, 0, 0);
+            float radiance = 0.0f, u0 = 0.0f, u1 = 0.0f, u2 = 0.0f;
+            if (v < nverts) {
+                const size_t k = (size_t)v * gp.row_stride + pid;
+                pp = gp.vtx.p_pdf[k];
+                wi = gp.vtx.wi[k];
+                radiance = spec_average(l) / pp.w;
+                want = isfinite(radiance) && radiance != 0.0f;  // STree::record's early return (stree.rs:102-116)
+                if (want) {
+                    u0 = rng_f32(rng);
+                    u1 = rng_f32(rng);
+                    u2 = rng_f32(rng);
+                }
+                l = l * load_spec(gp.vtx.f0, gp.vtx.f1, k);
+                l = l + load_spec(gp.vtx.li0, gp.vtx.li1, k);
+                l = l + load_spec(gp.vtx.e0, gp.vtx.e1, k);
+            }
+            const unsigned long long m = __ballot(want);
+            if (m != 0ull) {
+                uint32_t wbase = 0;
+                if (lane == 0) wbase = atomicAdd(&sm_n, (uint32_t)__popcll(m));
+                wbase = __shfl(wbase, 0);
+                if (want) {
+                    const size_t slot = base + wbase + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                    rq.q0[slot] = make_float4(pp.x, pp.y, pp.z, radiance);
+                    rq.q1[slot] = make_float4(wi.x, wi.y, wi.z, u0);
+                    rq.q2[slot] = make_float2(u1, u2);
+                }
+            }
         }
-        if (gp.write_film) {
+        if (valid && gp.write_film) {
             const Lambdas wl = load_lambdas(rp.lambda_tab, rp4.w & 0xffffu, true);
             film_add(sc, rp.film, rp4.z, l, wl, (flags & FLAG_SECONDARY_TERMINATED) != 0);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) rq.count[chunk] = sm_n;
+    }
+}
+
+// STree::record with the stochastic spatial filter (stree.rs:102-116,186-201) for the queued records.
+__global__ __launch_bounds__(kBlock) void k_guide_splat(SdTreeDev tree, GuidedParams gp, RecordQueue rq, uint32_t n_paths) {
+    const uint32_t n_chunks = (n_paths + kBlock - 1) / kBlock;
+    for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+        const uint32_t n = rq.count[chunk];
+        const size_t base = (size_t)chunk * kBlock * gp.n_rows;
+        for (uint32_t j = threadIdx.x; j < n; j += kBlock) {
+            const float4 a = rq.q0[base + j], b = rq.q1[base + j];
+            const float2 c = rq.q2[base + j];
+            stree_record_jittered(tree, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), a.w, b.w, c.x, c.y);
         }
     }
 }

@@ -78,6 +78,7 @@ struct VertexCols {
     float4* li1;
 };
 constexpr size_t kVertexBytes = 8 * 16;
+constexpr size_t kRecordBytes = 40;  // record-queue entry per vertex (pt_guided.h: RecordQueue)
 struct PathTail {     // per path id, written when the walk ends (guided)
     uint4* rng_px;    // final PCG state lo, hi, pixel, wavelength-table index
     uint32_t* nverts_flags;  // vertex count | FLAG_SECONDARY_TERMINATED
