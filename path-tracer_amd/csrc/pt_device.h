@@ -332,12 +332,24 @@ PT_HD bool ray_triangle(V3 ro, const RayShear& rs, V3 p0, V3 p1, V3 p2, float ma
 // their left child at index+1 and `offset` = right child. The visit order (far child pushed first, near on
 // top), the box test against the ORIGINAL ray_end_t and the "later triangle wins ties" rule are the
 // reference's, so the reported primitive is the same one bit for bit.
+//
+// Shape of the loop (CDNA4): the reference never culls boxes by the current hit, so which nodes a ray visits does
+// not depend on what it hits. That allows a "while-while" walk — every lane first descends boxes until it stands on
+// a leaf, then all lanes test their leaf's triangles together — instead of mixing box and triangle work in one
+// divergent loop body. The near child stays in a register; the far-child stack lives in LDS (column `threadIdx.x` of
+// a [depth][256] array, conflict-free, sized from the tree's depth at launch) instead of scratch memory.
 struct Hit {
     uint32_t prim;  // leaf-order triangle index, kNoHit = miss
     TriHit th;
 };
-template <bool COUNT>
+// ANY_HIT (occlusion queries only): Scene::occluded keeps no more than "was anything hit" (scene.rs:229-235). Once
+// a triangle is accepted clearly inside the segment, later triangles can only be accepted at t <= best (up to a few
+// ulps), so the answer `best.t != ray_end_t` is already decided and the walk stops. Hits within 0.1 % of the end
+// keep walking so that the reference's exact-equality rule (bvh.rs:137) sees the same final t.
+template <bool COUNT, bool ANY_HIT = false>
 PT_D Hit bvh_intersect(const SceneDev& sc, V3 o, V3 d, float ray_end_t, uint32_t* n_nodes_visited, uint32_t* n_tris_tested) {
+    extern __shared__ uint32_t sm_bvh_stack[];
+    uint32_t* stack = sm_bvh_stack + threadIdx.x;
     Hit best;
     best.prim = kNoHit;
     best.th.t = ray_end_t;
@@ -346,65 +358,72 @@ PT_D Hit bvh_intersect(const SceneDev& sc, V3 o, V3 d, float ray_end_t, uint32_t
     const bool nx = inv.x < 0.0f, ny = inv.y < 0.0f, nz = inv.z < 0.0f;
     const float slack = 1.0f + 2.0f * gamma_n(3.0f);
     const RayShear shear = ray_shear(d);
-    uint32_t stack[kBvhStack];
-    int sp = 0;
-    stack[sp++] = 0;
-    while (sp > 0) {
-        const uint32_t ni = stack[--sp];
-        const float4 n0 = sc.nodes[2 * ni], n1 = sc.nodes[2 * ni + 1];
-        if (COUNT) (*n_nodes_visited)++;
-        float tmin = 0.0f, tmax = ray_end_t;
-        {
-            float near_x = nx ? n1.x : n0.x, far_x = nx ? n0.x : n1.x;
-            float t0 = inv.x * (near_x - o.x);
-            float t1 = slack * inv.x * (far_x - o.x);
-            tmin = fmaxf(tmin, t0);
-            tmax = fminf(tmax, t1);
-            float near_y = ny ? n1.y : n0.y, far_y = ny ? n0.y : n1.y;
-            t0 = inv.y * (near_y - o.y);
-            t1 = slack * inv.y * (far_y - o.y);
-            tmin = fmaxf(tmin, t0);
-            tmax = fminf(tmax, t1);
-            float near_z = nz ? n1.z : n0.z, far_z = nz ? n0.z : n1.z;
-            t0 = inv.z * (near_z - o.z);
-            t1 = slack * inv.z * (far_z - o.z);
-            tmin = fmaxf(tmin, t0);
-            tmax = fminf(tmax, t1);
-        }
-        if (!((0.0f <= tmin) && (tmin <= tmax))) continue;
-        const uint32_t offset = f2u(n0.w), meta = f2u(n1.w);
-        const uint32_t ntris = meta & 0xffffu;
-        if (ntris > 0) {
-            for (uint32_t k = offset; k < offset + ntris; k++) {
-                const float4 a = sc.tri_v[3 * k], b = sc.tri_v[3 * k + 1], c = sc.tri_v[3 * k + 2];
-                if (COUNT) (*n_tris_tested)++;
-                TriHit th;
-                if (ray_triangle(o, shear, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), best.th.t, th)) {
-                    best.th = th;
-                    best.prim = k;
+    uint32_t sp = 0;
+    uint32_t ni = 0;
+    bool have_node = true;
+    for (;;) {
+        uint32_t leaf_first = 0, leaf_n = 0;
+        while (have_node) {
+            const float4 n0 = sc.nodes[2 * ni], n1 = sc.nodes[2 * ni + 1];
+            if (COUNT) (*n_nodes_visited)++;
+            float tmin = 0.0f, tmax = ray_end_t;
+            {
+                float near_x = nx ? n1.x : n0.x, far_x = nx ? n0.x : n1.x;
+                float t0 = inv.x * (near_x - o.x);
+                float t1 = slack * inv.x * (far_x - o.x);
+                tmin = fmaxf(tmin, t0);
+                tmax = fminf(tmax, t1);
+                float near_y = ny ? n1.y : n0.y, far_y = ny ? n0.y : n1.y;
+                t0 = inv.y * (near_y - o.y);
+                t1 = slack * inv.y * (far_y - o.y);
+                tmin = fmaxf(tmin, t0);
+                tmax = fminf(tmax, t1);
+                float near_z = nz ? n1.z : n0.z, far_z = nz ? n0.z : n1.z;
+                t0 = inv.z * (near_z - o.z);
+                t1 = slack * inv.z * (far_z - o.z);
+                tmin = fmaxf(tmin, t0);
+                tmax = fminf(tmax, t1);
+            }
+            if ((0.0f <= tmin) && (tmin <= tmax)) {
+                const uint32_t offset = f2u(n0.w), meta = f2u(n1.w);
+                const uint32_t ntris = meta & 0xffffu;
+                if (ntris == 0) {
+                    const uint32_t axis = meta >> 16;
+                    const bool neg = axis == 0 ? nx : (axis == 1 ? ny : nz);
+                    if (sp < sc.bvh_stack) {  // holds for every tree scene_create accepts
+                        stack[sp * kBlock] = neg ? ni + 1 : offset;  // far child waits
+                        sp++;
+                        ni = neg ? offset : ni + 1;                  // near child is next
+                        continue;
+                    }
+                } else {
+                    leaf_first = offset;
+                    leaf_n = ntris;
                 }
             }
-        } else {
-            const uint32_t axis = meta >> 16;
-            const bool neg = axis == 0 ? nx : (axis == 1 ? ny : nz);
-            if (sp + 2 <= kBvhStack) {
-                if (neg) {
-                    stack[sp++] = ni + 1;
-                    stack[sp++] = offset;
-                } else {
-                    stack[sp++] = offset;
-                    stack[sp++] = ni + 1;
-                }
+            if (sp > 0) ni = stack[(--sp) * kBlock];
+            else have_node = false;
+            if (leaf_n) break;
+        }
+        if (leaf_n == 0) break;
+        for (uint32_t k = leaf_first; k < leaf_first + leaf_n; k++) {
+            const float4 a = sc.tri_v[3 * k], b = sc.tri_v[3 * k + 1], c = sc.tri_v[3 * k + 2];
+            if (COUNT) (*n_tris_tested)++;
+            TriHit th;
+            if (ray_triangle(o, shear, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), best.th.t, th)) {
+                best.th = th;
+                best.prim = k;
+                if (ANY_HIT && th.t < 0.999f * ray_end_t) return best;
             }
         }
     }
     if (!(best.th.t != ray_end_t)) best.prim = kNoHit;  // bvh.rs:137
     return best;
 }
-// Scene::occluded (scene.rs:229-235): unnormalised segment, t_max 0.9999, full closest-hit like Bvh::hit.
+// Scene::occluded (scene.rs:229-235): unnormalised segment, t_max 0.9999; only the boolean leaves this function.
 template <bool COUNT = false>
 PT_D bool scene_occluded(const SceneDev& sc, V3 from, V3 to, uint32_t* n_nodes = nullptr, uint32_t* n_tris = nullptr) {
-    Hit h = bvh_intersect<COUNT>(sc, from, to - from, 0.9999f, n_nodes, n_tris);
+    Hit h = bvh_intersect<COUNT, true>(sc, from, to - from, 0.9999f, n_nodes, n_tris);
     return h.prim != kNoHit;
 }
 

@@ -7,7 +7,7 @@
 
 namespace pt {
 
-constexpr int kBlock = 256;
+// kBlock (threads per workgroup) is defined in pt_types.h
 #ifndef PT_SHADE_WAVES
 #define PT_SHADE_WAVES 2  // minimum waves per SIMD the shade kernels are compiled for (register budget 512 / N)
 #endif

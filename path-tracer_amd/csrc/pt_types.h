@@ -7,6 +7,7 @@ namespace pt {
 constexpr int NSW = 8;          // N_SAMPLED_WAVELENGTHS (pt/src/spectrum/mod.rs:6)
 constexpr int CIE_N = 471;      // 360..830 nm, 1 nm
 constexpr uint32_t kNoHit = 0xffffffffu;
+constexpr int kBlock = 256;     // threads per workgroup of every kernel
 constexpr int kBvhStack = 64;   // ArrayVec<usize, 64> (pt/src/bvh.rs:94)
 
 enum { MAT_LAMBERTIAN = 0, MAT_DIELECTRIC = 1, MAT_CONDUCTOR = 2 };
@@ -40,6 +41,7 @@ struct SceneDev {
     const float* d65;                  // CIE_D65_F32[471]
     const double* cie_xyz;             // CIE_XYZ_F64[471][3]
     uint32_t n_nodes, n_tris, n_emissive_tris, n_emissive_meshes;
+    uint32_t bvh_stack;                // LDS stack entries per ray = tree depth + 1 (kernels get 256 * bvh_stack * 4 B of dynamic LDS)
     V3 bounds_lo, bounds_hi;
 };
 

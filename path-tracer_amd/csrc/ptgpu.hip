@@ -110,6 +110,7 @@ struct ptgpu_ctx {
     std::vector<hipEvent_t> ev_pool;
     std::vector<int> ev_stage;  // stage of pair i (events 2i, 2i+1)
     bool census_on = false;
+    size_t bvh_lds = 0;  // dynamic LDS bytes of every kernel that walks the BVH (pt_device.h: bvh_intersect)
     DevBuf<unsigned long long> d_census;  // extend nodes, extend tris, occlude nodes, occlude tris
     double stage_ms[PTGPU_N_STAGES] = {0, 0, 0, 0, 0, 0};
     uint64_t stage_launches[PTGPU_N_STAGES] = {0, 0, 0, 0, 0, 0};
@@ -292,6 +293,21 @@ int ptgpu_scene_create(ptgpu_ctx* c, const ptgpu_scene_desc* desc) {
     if (!build_bvh(build, bvh)) return fail(PTGPU_E_LIMIT, "scene_create: a BVH leaf exceeds 65535 triangles");
 
     const size_t n_tris = bvh.leaf_order.size(), n_nodes = bvh.nodes.size();
+    // deepest leaf: the traversal keeps at most one waiting sibling per level
+    uint32_t bvh_depth = 0;
+    {
+        std::vector<std::pair<uint32_t, uint32_t>> todo{{0u, 0u}};
+        while (!todo.empty()) {
+            const auto [ni, depth] = todo.back();
+            todo.pop_back();
+            bvh_depth = std::max(bvh_depth, depth);
+            if (bvh.nodes[ni].n_tris == 0) {
+                todo.emplace_back(ni + 1, depth + 1);
+                todo.emplace_back(bvh.nodes[ni].offset, depth + 1);
+            }
+        }
+    }
+    if (bvh_depth + 1 > (uint32_t)kBvhStack) return fail(PTGPU_E_LIMIT, "scene_create: BVH deeper than the reference's 64-entry traversal stack (bvh.rs:94)");
     std::vector<float4> nodes(2 * n_nodes), tri_v(3 * n_tris), tri_n(3 * n_tris, make_float4(0, 0, 0, 0));
     c->h_nodes_words.assign(8 * n_nodes, 0);
     for (size_t i = 0; i < n_nodes; i++) {
@@ -360,6 +376,8 @@ int ptgpu_scene_create(ptgpu_ctx* c, const ptgpu_scene_desc* desc) {
     s.n_tris = (uint32_t)n_tris;
     s.n_emissive_tris = (uint32_t)emissive_ids.size();
     s.n_emissive_meshes = n_emissive_meshes;
+    s.bvh_stack = bvh_depth + 1;
+    c->bvh_lds = (size_t)kBlock * s.bvh_stack * sizeof(uint32_t);
     s.bounds_lo = bvh.nodes[0].bounds.lo;
     s.bounds_hi = bvh.nodes[0].bounds.hi;
     c->have_scene = true;
@@ -438,7 +456,7 @@ int ptgpu_trace_batch(ptgpu_ctx* c, const float* rays, uint32_t n, ptgpu_hit* hi
     HIP_TRY(d_rays.alloc(7 * (size_t)n));
     HIP_TRY(d_hits.alloc(n));
     HIP_TRY(hipMemcpyAsync(d_rays.p, rays, 7 * (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(k_trace_batch, dim3(grid_for(c, n)), dim3(kBlock), 0, c->stream, c->scene, d_rays.p, n, d_hits.p, (unsigned long long*)nullptr);
+    hipLaunchKernelGGL(k_trace_batch, dim3(grid_for(c, n)), dim3(kBlock), c->bvh_lds, c->stream, c->scene, d_rays.p, n, d_hits.p, (unsigned long long*)nullptr);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(hits_out, d_hits.p, (size_t)n * sizeof(HitOut), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -457,7 +475,7 @@ int ptgpu_occluded_batch(ptgpu_ctx* c, const float* from, const float* to, uint3
     HIP_TRY(d_out.alloc(n));
     HIP_TRY(hipMemcpyAsync(d_from.p, from, 3 * (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(d_to.p, to, 3 * (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(k_occluded_batch, dim3(grid_for(c, n)), dim3(kBlock), 0, c->stream, c->scene, d_from.p, d_to.p, n, d_out.p);
+    hipLaunchKernelGGL(k_occluded_batch, dim3(grid_for(c, n)), dim3(kBlock), c->bvh_lds, c->stream, c->scene, d_from.p, d_to.p, n, d_out.p);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(out, d_out.p, n, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -504,8 +522,8 @@ int ptgpu_set_batch_paths(ptgpu_ctx* c, uint32_t n_paths) {
 namespace {
 
 void launch_extend(ptgpu_ctx* c, int grid, const PathCols& A, const HitCols& H, const RoundCounters* cnt) {
-    if (c->census_on) hipLaunchKernelGGL(k_extend<true>, dim3(grid), dim3(kBlock), 0, c->stream, c->scene, A, H, cnt, c->d_census.p);
-    else hipLaunchKernelGGL(k_extend<false>, dim3(grid), dim3(kBlock), 0, c->stream, c->scene, A, H, cnt, c->d_census.p);
+    if (c->census_on) hipLaunchKernelGGL(k_extend<true>, dim3(grid), dim3(kBlock), c->bvh_lds, c->stream, c->scene, A, H, cnt, c->d_census.p);
+    else hipLaunchKernelGGL(k_extend<false>, dim3(grid), dim3(kBlock), c->bvh_lds, c->stream, c->scene, A, H, cnt, c->d_census.p);
 }
 
 int upload_lambda_table(ptgpu_ctx* c, const std::vector<float>& u) {
@@ -542,8 +560,8 @@ int run_batch_path_like(ptgpu_ctx* c, bool light, const RenderParams& rp, uint32
             hipLaunchKernelGGL(k_raygen_light, dim3(grid), dim3(kBlock), 0, c->stream, c->scene, c->camera, rp, A, S, cnt, n_paths, npix, first_sample, sample_step);
         }
         StageTimer t(c, PTGPU_STAGE_OCCLUDE);
-        if (c->census_on) hipLaunchKernelGGL(k_occlude_splat<true>, dim3(grid), dim3(kBlock), 0, c->stream, c->scene, rp, S, cnt, c->d_census.p);
-        else hipLaunchKernelGGL(k_occlude_splat<false>, dim3(grid), dim3(kBlock), 0, c->stream, c->scene, rp, S, cnt, c->d_census.p);
+        if (c->census_on) hipLaunchKernelGGL(k_occlude_splat<true>, dim3(grid), dim3(kBlock), c->bvh_lds, c->stream, c->scene, rp, S, cnt, c->d_census.p);
+        else hipLaunchKernelGGL(k_occlude_splat<false>, dim3(grid), dim3(kBlock), c->bvh_lds, c->stream, c->scene, rp, S, cnt, c->d_census.p);
     } else {
         StageTimer t(c, PTGPU_STAGE_RAYGEN);
         hipLaunchKernelGGL(k_raygen_camera, dim3(grid), dim3(kBlock), 0, c->stream, c->scene, c->camera, rp, A, cnt, n_paths, npix, first_sample, sample_step);
@@ -568,11 +586,11 @@ int run_batch_path_like(ptgpu_ctx* c, bool light, const RenderParams& rp, uint32
         {
             StageTimer t(c, PTGPU_STAGE_OCCLUDE);
             if (light) {
-                if (c->census_on) hipLaunchKernelGGL(k_occlude_splat<true>, dim3(grid), dim3(kBlock), 0, c->stream, c->scene, rp, S, cnt + round + 1, c->d_census.p);
-                else hipLaunchKernelGGL(k_occlude_splat<false>, dim3(grid), dim3(kBlock), 0, c->stream, c->scene, rp, S, cnt + round + 1, c->d_census.p);
+                if (c->census_on) hipLaunchKernelGGL(k_occlude_splat<true>, dim3(grid), dim3(kBlock), c->bvh_lds, c->stream, c->scene, rp, S, cnt + round + 1, c->d_census.p);
+                else hipLaunchKernelGGL(k_occlude_splat<false>, dim3(grid), dim3(kBlock), c->bvh_lds, c->stream, c->scene, rp, S, cnt + round + 1, c->d_census.p);
             } else {
-                if (c->census_on) hipLaunchKernelGGL(k_occlude_path<true>, dim3(grid), dim3(kBlock), 0, c->stream, c->scene, rp, B, S, cnt + round + 1, c->d_census.p);
-                else hipLaunchKernelGGL(k_occlude_path<false>, dim3(grid), dim3(kBlock), 0, c->stream, c->scene, rp, B, S, cnt + round + 1, c->d_census.p);
+                if (c->census_on) hipLaunchKernelGGL(k_occlude_path<true>, dim3(grid), dim3(kBlock), c->bvh_lds, c->stream, c->scene, rp, B, S, cnt + round + 1, c->d_census.p);
+                else hipLaunchKernelGGL(k_occlude_path<false>, dim3(grid), dim3(kBlock), c->bvh_lds, c->stream, c->scene, rp, B, S, cnt + round + 1, c->d_census.p);
             }
         }
         HIP_TRY(hipGetLastError());
