@@ -337,7 +337,9 @@ PT_HD bool ray_triangle(V3 ro, const RayShear& rs, V3 p0, V3 p1, V3 p2, float ma
 // not depend on what it hits. That allows a "while-while" walk — every lane first descends boxes until it stands on
 // a leaf, then all lanes test their leaf's triangles together — instead of mixing box and triangle work in one
 // divergent loop body. The near child stays in a register; the far-child stack lives in LDS (column `threadIdx.x` of
-// a [depth][256] array, conflict-free, sized from the tree's depth at launch) instead of scratch memory.
+// a [depth][256] array, conflict-free, sized from the tree's depth at launch) instead of scratch memory. Up to
+// kLeafQueue leaves wait (in LDS as well) before the triangle phase starts, so a lane with many small leaves does not
+// force the whole wave through one box phase per leaf; leaves and triangles are still tested in the reference's order.
 struct Hit {
     uint32_t prim;  // leaf-order triangle index, kNoHit = miss
     TriHit th;
@@ -358,12 +360,13 @@ PT_D Hit bvh_intersect(const SceneDev& sc, V3 o, V3 d, float ray_end_t, uint32_t
     const bool nx = inv.x < 0.0f, ny = inv.y < 0.0f, nz = inv.z < 0.0f;
     const float slack = 1.0f + 2.0f * gamma_n(3.0f);
     const RayShear shear = ray_shear(d);
+    uint32_t* pend = sm_bvh_stack + sc.bvh_stack * kBlock + threadIdx.x;  // leaves waiting for their triangle tests
     uint32_t sp = 0;
     uint32_t ni = 0;
     bool have_node = true;
     for (;;) {
-        uint32_t leaf_first = 0, leaf_n = 0;
-        while (have_node) {
+        uint32_t n_pend = 0;
+        while (have_node && n_pend < kLeafQueue) {
             const float4 n0 = sc.nodes[2 * ni], n1 = sc.nodes[2 * ni + 1];
             if (COUNT) (*n_nodes_visited)++;
             float tmin = 0.0f, tmax = ray_end_t;
@@ -397,23 +400,26 @@ PT_D Hit bvh_intersect(const SceneDev& sc, V3 o, V3 d, float ray_end_t, uint32_t
                         continue;
                     }
                 } else {
-                    leaf_first = offset;
-                    leaf_n = ntris;
+                    pend[(2 * n_pend) * kBlock] = offset;
+                    pend[(2 * n_pend + 1) * kBlock] = ntris;
+                    n_pend++;
                 }
             }
             if (sp > 0) ni = stack[(--sp) * kBlock];
             else have_node = false;
-            if (leaf_n) break;
         }
-        if (leaf_n == 0) break;
-        for (uint32_t k = leaf_first; k < leaf_first + leaf_n; k++) {
-            const float4 a = sc.tri_v[3 * k], b = sc.tri_v[3 * k + 1], c = sc.tri_v[3 * k + 2];
-            if (COUNT) (*n_tris_tested)++;
-            TriHit th;
-            if (ray_triangle(o, shear, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), best.th.t, th)) {
-                best.th = th;
-                best.prim = k;
-                if (ANY_HIT && th.t < 0.999f * ray_end_t) return best;
+        if (n_pend == 0) break;
+        for (uint32_t j = 0; j < n_pend; j++) {
+            const uint32_t leaf_first = pend[(2 * j) * kBlock], leaf_n = pend[(2 * j + 1) * kBlock];
+            for (uint32_t k = leaf_first; k < leaf_first + leaf_n; k++) {
+                const float4 a = sc.tri_v[3 * k], b = sc.tri_v[3 * k + 1], c = sc.tri_v[3 * k + 2];
+                if (COUNT) (*n_tris_tested)++;
+                TriHit th;
+                if (ray_triangle(o, shear, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), best.th.t, th)) {
+                    best.th = th;
+                    best.prim = k;
+                    if (ANY_HIT && th.t < 0.999f * ray_end_t) return best;
+                }
             }
         }
     }

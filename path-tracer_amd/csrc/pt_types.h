@@ -8,6 +8,10 @@ constexpr int NSW = 8;          // N_SAMPLED_WAVELENGTHS (pt/src/spectrum/mod.rs
 constexpr int CIE_N = 471;      // 360..830 nm, 1 nm
 constexpr uint32_t kNoHit = 0xffffffffu;
 constexpr int kBlock = 256;     // threads per workgroup of every kernel
+#ifndef PT_LEAF_QUEUE
+#define PT_LEAF_QUEUE 4
+#endif
+constexpr uint32_t kLeafQueue = PT_LEAF_QUEUE;  // leaves a ray collects before testing their triangles (pt_device.h)
 constexpr int kBvhStack = 64;   // ArrayVec<usize, 64> (pt/src/bvh.rs:94)
 
 enum { MAT_LAMBERTIAN = 0, MAT_DIELECTRIC = 1, MAT_CONDUCTOR = 2 };
