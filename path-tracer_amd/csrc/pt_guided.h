@@ -6,6 +6,24 @@
 
 namespace pt {
 
+// Build with -DPT_DBG_TIMING to attribute k_shade_guided's wave time to its sections (s_memtime deltas summed over
+// all waves into g_dbg_cycles; ptgpu_guided_end prints them). Compiled out otherwise.
+#ifdef PT_DBG_TIMING
+__device__ unsigned long long g_dbg_cycles[16];
+#define PT_TICK_INIT() long long dbg_last = clock64(); long long dbg_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define PT_TICK(k) do { const long long now_ = clock64(); dbg_acc[k] += now_ - dbg_last; dbg_last = now_; } while (0)
+#define PT_TICK_FLUSH() do { for (int k_ = 0; k_ < 12; k_++) { long long v_ = dbg_acc[k_]; for (int o_ = 32; o_ > 0; o_ >>= 1) { const long long w_ = __shfl_xor(v_, o_); v_ = w_ > v_ ? w_ : v_; } \
+        if (__lane_id() == 0) atomicAdd(&g_dbg_cycles[k_], (unsigned long long)v_); } } while (0)
+#define PT_DBG_PARAMS , long long& dbg_last, long long* dbg_acc
+#define PT_DBG_ARGS , dbg_last, dbg_acc
+#else
+#define PT_DBG_PARAMS
+#define PT_DBG_ARGS
+#define PT_TICK_INIT() do {} while (0)
+#define PT_TICK(k) do {} while (0)
+#define PT_TICK_FLUSH() do {} while (0)
+#endif
+
 struct GuidedState;  // host-side (ptgpu_guided_api.inc)
 void guided_free(GuidedState* g);
 
@@ -144,13 +162,14 @@ PT_D float dtree_pdf(const SdTreeDev& t, uint4 leaf, V2 p) {
 }
 
 // Guider::sample (path_guiding/mod.rs:315-368).
-PT_D bool guider_sample(const SdTreeDev& t, const Bsdf& bsdf, const Frame& fr, V3 ng, V3 p, V3 wo, Rng& rng, BsdfSample& s) {
+PT_D bool guider_sample(const SdTreeDev& t, const Bsdf& bsdf, const Frame& fr, V3 ng, V3 p, V3 wo, Rng& rng, BsdfSample& s PT_DBG_PARAMS) {
     if (t.iteration == 0 || bsdf_is_specular(bsdf)) {
         const float u1d = rng_f32(rng), ua = rng_f32(rng), ub = rng_f32(rng);
         return bsdf_sample(bsdf, fr, ng, wo, u1d, ua, ub, true, s);
     }
     V3 lo, hi;
     const uint4 leaf = t.leaf_info[stree_leaf(t, p, lo, hi)];
+    PT_TICK(3);
     // Both branches need the tree's pdf at the chosen direction; the quadtree descent is hoisted out of the branch
     // so a wave walks it once with all lanes instead of twice with half of them. Values are unchanged.
     const bool use_tree = rng_f32(rng) < 0.5f;
@@ -158,12 +177,16 @@ PT_D bool guider_sample(const SdTreeDev& t, const Bsdf& bsdf, const Frame& fr, V
     if (use_tree) {
         sq = dtree_sample(t, leaf, rng);
         s.wi = square_to_dir(sq);
+        PT_TICK(4);
     } else {
         const float u1d = rng_f32(rng), ua = rng_f32(rng), ub = rng_f32(rng);
         if (!bsdf_sample(bsdf, fr, ng, wo, u1d, ua, ub, true, s)) return false;
         sq = dir_to_square(s.wi);
+        PT_TICK(5);
     }
+    PT_TICK(4);
     const float tree_pdf = dtree_pdf(t, leaf, sq);
+    PT_TICK(6);
     if (use_tree) {
         const float bp = bsdf_pdf(bsdf, fr, wo, s.wi) * 0.5f;
         if (bp == 0.0f) return false;  // the tree proposed a direction the BSDF cannot produce: the walk ends here
@@ -171,9 +194,11 @@ PT_D bool guider_sample(const SdTreeDev& t, const Bsdf& bsdf, const Frame& fr, V
         s.f = bsdf_eval(bsdf, fr, ng, wo, s.wi, true);
         s.specular = false;
         s.terminate_secondary = false;
+        PT_TICK(7);
     } else {
         s.pdf = 0.5f * s.pdf + 0.5f * tree_pdf;
     }
+    PT_TICK(7);
     return true;
 }
 
@@ -237,7 +262,7 @@ PT_D void stree_record_jittered(const SdTreeDev& t, V3 p, V3 wi, float radiance,
 }
 
 struct GuidedParams {
-    VertexCols vtx;
+    VertexStore vtx;
     PathTail tail;
     uint32_t n_rows;       // max_depth + 1 vertex rows
     uint32_t row_stride;   // = capacity
@@ -294,13 +319,15 @@ __global__ __launch_bounds__(kBlock) void k_raygen_guided(SceneDev sc, CameraDev
 }
 
 PT_D void store_vertex(const GuidedParams& gp, uint32_t row, uint32_t pid, V3 p, V3 wi, float pdf, const Spec& f, const Spec& e) {
-    const size_t k = (size_t)row * gp.row_stride + pid;
-    gp.vtx.p_pdf[k] = make_float4(p.x, p.y, p.z, pdf);
-    gp.vtx.wi[k] = make_float4(wi.x, wi.y, wi.z, 0.0f);
-    store_spec(gp.vtx.f0, gp.vtx.f1, k, f);
-    store_spec(gp.vtx.e0, gp.vtx.e1, k, e);
-    gp.vtx.li0[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    gp.vtx.li1[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    float4* v = gp.vtx.at(row, pid);
+    v[VTX_P_PDF] = make_float4(p.x, p.y, p.z, pdf);
+    v[VTX_WI] = make_float4(wi.x, wi.y, wi.z, 0.0f);
+    v[VTX_F0] = make_float4(f.v[0], f.v[1], f.v[2], f.v[3]);
+    v[VTX_F1] = make_float4(f.v[4], f.v[5], f.v[6], f.v[7]);
+    v[VTX_E0] = make_float4(e.v[0], e.v[1], e.v[2], e.v[3]);
+    v[VTX_E1] = make_float4(e.v[4], e.v[5], e.v[6], e.v[7]);
+    v[VTX_LI0] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    v[VTX_LI1] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 }
 
 // One iteration of PathGuidingIntegrator::random_walk's loop body (mod.rs:139-278).
@@ -308,6 +335,7 @@ __global__ __launch_bounds__(kBlock, PT_SHADE_WAVES) void k_shade_guided(SceneDe
                                                          ShadowCols sh, const RoundCounters* cur, RoundCounters* nxt) {
     __shared__ BlockAlloc sm_alloc;
     __shared__ uint32_t sm_count;
+    PT_TICK_INIT();
     uint32_t n_shaded = 0, n_skipped = 0;
     const uint32_t n = cur->n_active;
     const uint32_t stride = gridDim.x * blockDim.x;
@@ -332,6 +360,7 @@ __global__ __launch_bounds__(kBlock, PT_SHADE_WAVES) void k_shade_guided(SceneDe
             pid = f2u(pp.w);
             nverts = rp4.w >> 16;
             const uint32_t prim = hit.prim[i];
+            PT_TICK(0);
             if (prim == kNoHit) {
                 // miss vertex (mod.rs:140-150): far point along the ray, nothing emitted without an envmap
                 if (nverts < gp.n_rows) {
@@ -371,6 +400,7 @@ __global__ __launch_bounds__(kBlock, PT_SHADE_WAVES) void k_shade_guided(SceneDe
                         }
                     }
                     Rng rng{(uint64_t)rp4.x | ((uint64_t)rp4.y << 32), rng_inc_for_pixel(rp4.z % rp.resx, rp4.z / rp.resx)};
+                    PT_TICK(1);
                     bool has_nee = false;
                     if (rp.mode != MODE_PT && !specular) {
                         const float u1d = rng_f32(rng), ua = rng_f32(rng), ub = rng_f32(rng);
@@ -396,8 +426,9 @@ __global__ __launch_bounds__(kBlock, PT_SHADE_WAVES) void k_shade_guided(SceneDe
                             }
                         }
                     }
+                    PT_TICK(2);
                     BsdfSample bs;
-                    const bool ok = guider_sample(tree, bsdf, sf.frame, sf.ng, p, wo, rng, bs);
+                    const bool ok = guider_sample(tree, bsdf, sf.frame, sf.ng, p, wo, rng, bs PT_DBG_ARGS);
                     rp4.x = (uint32_t)rng.state;
                     rp4.y = (uint32_t)(rng.state >> 32);
                     if (!ok) {
@@ -436,8 +467,10 @@ __global__ __launch_bounds__(kBlock, PT_SHADE_WAVES) void k_shade_guided(SceneDe
             }
             rp4.w = (rp4.w & 0xffffu) | (nverts << 16);
         }
+        PT_TICK(8);
         uint32_t a_slot, s_slot;
         block_alloc2(sm_alloc, nxt, alive, want_shadow, a_slot, s_slot);
+        PT_TICK(9);
         n_shaded += shaded ? 1u : 0u;
         n_skipped += skipped_shadow ? 1u : 0u;
         if (alive) {
@@ -456,9 +489,12 @@ __global__ __launch_bounds__(kBlock, PT_SHADE_WAVES) void k_shade_guided(SceneDe
             sh.q1[s_slot] = make_float4(sh_to.x, sh_to.y, sh_to.z, u2f(shadow_row));
             store_spec(sh.q2, sh.q3, s_slot, contrib);
         }
+        PT_TICK(10);
     }
     block_count_flush(&sm_count, &nxt->n_segments, n_shaded);
     block_count_flush(&sm_count, &nxt->n_terminal, n_skipped);
+    PT_TICK(11);
+    PT_TICK_FLUSH();
 }
 
 // NEE visibility for the guided walk: an unoccluded sample becomes the vertex's li_sample_contribution.
@@ -470,9 +506,9 @@ __global__ __launch_bounds__(kBlock) void k_occlude_guided(SceneDev sc, GuidedPa
     for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) {
         const float4 a = sh.q0[j], b = sh.q1[j];
         if (!scene_occluded<CENSUS>(sc, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), &cn, &ct)) {
-            const size_t k = (size_t)f2u(b.w) * gp.row_stride + f2u(a.w);
-            gp.vtx.li0[k] = sh.q2[j];
-            gp.vtx.li1[k] = sh.q3[j];
+            float4* v = gp.vtx.at(f2u(b.w), f2u(a.w));
+            v[VTX_LI0] = sh.q2[j];
+            v[VTX_LI1] = sh.q3[j];
         }
     }
     if (CENSUS) census_add(census, 2, cn, ct);
@@ -520,9 +556,9 @@ __global__ __launch_bounds__(kBlock) void k_guide_scan(SceneDev sc, RenderParams
             float4 pp = make_float4(0, 0, 0, 0), wi = make_float4(0, 0, 0, 0);
             float radiance = 0.0f, u0 = 0.0f, u1 = 0.0f, u2 = 0.0f;
             if (v < nverts) {
-                const size_t k = (size_t)v * gp.row_stride + pid;
-                pp = gp.vtx.p_pdf[k];
-                wi = gp.vtx.wi[k];
+                const float4* vx = gp.vtx.at(v, pid);
+                pp = vx[VTX_P_PDF];
+                wi = vx[VTX_WI];
                 radiance = spec_average(l) / pp.w;
                 want = isfinite(radiance) && radiance != 0.0f;  // STree::record's early return (stree.rs:102-116)
                 if (want) {
@@ -530,9 +566,9 @@ __global__ __launch_bounds__(kBlock) void k_guide_scan(SceneDev sc, RenderParams
                     u1 = rng_f32(rng);
                     u2 = rng_f32(rng);
                 }
-                l = l * load_spec(gp.vtx.f0, gp.vtx.f1, k);
-                l = l + load_spec(gp.vtx.li0, gp.vtx.li1, k);
-                l = l + load_spec(gp.vtx.e0, gp.vtx.e1, k);
+                l = l * spec_from(vx[VTX_F0], vx[VTX_F1]);
+                l = l + spec_from(vx[VTX_LI0], vx[VTX_LI1]);
+                l = l + spec_from(vx[VTX_E0], vx[VTX_E1]);
             }
             const unsigned long long m = __ballot(want);
             if (m != 0ull) {

@@ -93,6 +93,12 @@ PT_D Spec load_spec(const float4* a, const float4* b, uint32_t i) {
     s.v[4] = y.x; s.v[5] = y.y; s.v[6] = y.z; s.v[7] = y.w;
     return s;
 }
+PT_D Spec spec_from(float4 a, float4 b) {
+    Spec s;
+    s.v[0] = a.x; s.v[1] = a.y; s.v[2] = a.z; s.v[3] = a.w;
+    s.v[4] = b.x; s.v[5] = b.y; s.v[6] = b.z; s.v[7] = b.w;
+    return s;
+}
 PT_D void store_spec(float4* a, float4* b, uint32_t i, const Spec& s) {
     a[i] = make_float4(s.v[0], s.v[1], s.v[2], s.v[3]);
     b[i] = make_float4(s.v[4], s.v[5], s.v[6], s.v[7]);

@@ -65,18 +65,17 @@ struct RoundCounters {
 };
 constexpr int kMaxRounds = 1 << 16;
 
-// Guided integrator: per-path vertex store (PathVertex, path_guiding/mod.rs:281-289), vertex-major so that the
-// record pass (one lane per path) reads row v of every path coalesced: column[v * n_paths + path_id].
-struct VertexCols {
-    float4* p_pdf;    // p.xyz, wi_pdf
-    float4* wi;       // wi.xyz, -
-    float4* f0;       // f / pdf
-    float4* f1;
-    float4* e0;       // emitted
-    float4* e1;
-    float4* li0;      // li_sample_contribution (zero unless the shadow ray was unoccluded)
-    float4* li1;
+// Guided integrator: per-path vertex store (PathVertex, path_guiding/mod.rs:281-289). One vertex = one 128-byte
+// line of eight float4 {p.xyz|wi_pdf, wi.xyz|-, f/pdf (2), emitted (2), li_sample_contribution (2)}, the rows of a
+// path back to back: vertex (row, path) sits at line path * n_rows + row. Survivors are compacted every round, so
+// the lanes of a wave hold unrelated paths at different depths: whole-line records keep each lane's store (shade)
+// and load (record scan) one full line instead of eight scattered 16-byte pieces.
+struct VertexStore {
+    float4* lines;
+    uint32_t n_rows;
+    PT_HD float4* at(uint32_t row, uint32_t path) const { return lines + ((size_t)path * n_rows + row) * 8; }
 };
+enum { VTX_P_PDF = 0, VTX_WI = 1, VTX_F0 = 2, VTX_F1 = 3, VTX_E0 = 4, VTX_E1 = 5, VTX_LI0 = 6, VTX_LI1 = 7 };
 constexpr size_t kVertexBytes = 8 * 16;
 constexpr size_t kRecordBytes = 40;  // record-queue entry per vertex (pt_guided.h: RecordQueue)
 struct PathTail {     // per path id, written when the walk ends (guided)
