@@ -691,13 +691,22 @@ PT_D Surface make_surface(const SceneDev& sc, uint32_t prim, float b0, float b1,
     s.bhi = p + err;
     return s;
 }
+// KINDS = bit mask of the material kinds the scene uses (1 << MAT_*), fixed at scene creation. The shade kernels are
+// compiled per mask so that a scene without, say, conductors does not carry their registers and branches.
+template <int KINDS>
 PT_D Bsdf make_bsdf(const SceneDev& sc, int material, const Lambdas& wl) {
     const MaterialDev m = sc.materials[material];
     Bsdf b;
     b.kind = m.kind;
+    if (KINDS == (1 << MAT_LAMBERTIAN)) b.kind = MAT_LAMBERTIAN;
+    else if (KINDS == (1 << MAT_DIELECTRIC)) b.kind = MAT_DIELECTRIC;
+    else if (KINDS == (1 << MAT_CONDUCTOR)) b.kind = MAT_CONDUCTOR;
+    else if (!(KINDS & (1 << MAT_CONDUCTOR))) b.kind = m.kind == MAT_LAMBERTIAN ? MAT_LAMBERTIAN : MAT_DIELECTRIC;
+    else if (!(KINDS & (1 << MAT_DIELECTRIC))) b.kind = m.kind == MAT_LAMBERTIAN ? MAT_LAMBERTIAN : MAT_CONDUCTOR;
+    else if (!(KINDS & (1 << MAT_LAMBERTIAN))) b.kind = m.kind == MAT_DIELECTRIC ? MAT_DIELECTRIC : MAT_CONDUCTOR;
     b.roughness = m.roughness;
     b.a = spectrum_eval(m.s0, wl, sc.d65);
-    b.b = (m.kind == MAT_CONDUCTOR) ? spectrum_eval(m.s1, wl, sc.d65) : spec_splat(0.0f);
+    b.b = (b.kind == MAT_CONDUCTOR) ? spectrum_eval(m.s1, wl, sc.d65) : spec_splat(0.0f);
     return b;
 }
 

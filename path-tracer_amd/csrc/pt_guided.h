@@ -24,6 +24,10 @@ __device__ unsigned long long g_dbg_cycles[16];
 #define PT_TICK_FLUSH() do {} while (0)
 #endif
 
+#ifndef PT_GUIDED_DIFFUSE_WAVES
+#define PT_GUIDED_DIFFUSE_WAVES 2
+#endif
+
 struct GuidedState;  // host-side (ptgpu_guided_api.inc)
 void guided_free(GuidedState* g);
 
@@ -131,9 +135,10 @@ PT_D V2 dtree_sample(const SdTreeDev& t, uint4 leaf, Rng& rng) {
     }
 }
 // DTree::pdf (dtree.rs:155-179): prod over levels of 4 * child / sum, times 1 / 4 pi.
-PT_D float dtree_pdf(const SdTreeDev& t, uint4 leaf, V2 p) {
+// `scales` is this lane's column of a [kMaxQuadLevel + 1][kBlock] LDS array: the per-level factors are multiplied
+// innermost first, as the reference's recursion does, so they have to be kept until the leaf is reached.
+PT_D float dtree_pdf(const SdTreeDev& t, uint4 leaf, V2 p, float* scales) {
     if (leaf.z) return kInvFourPi;
-    float scales[kMaxQuadLevel + 1];
     int n = 0;
     uint32_t ni = 0;
     Cell cell{0, 0, 0};
@@ -153,16 +158,16 @@ PT_D float dtree_pdf(const SdTreeDev& t, uint4 leaf, V2 p) {
             result = scale;
             break;
         }
-        scales[n++] = scale;
+        scales[(n++) * kBlock] = scale;
         ni = link;
         cell = child;
     }
-    for (int i = n - 1; i >= 0; i--) result = scales[i] * result;  // innermost first, as the recursion multiplies
+    for (int i = n - 1; i >= 0; i--) result = scales[i * kBlock] * result;  // innermost first, as the recursion multiplies
     return result * kInvFourPi;
 }
 
 // Guider::sample (path_guiding/mod.rs:315-368).
-PT_D bool guider_sample(const SdTreeDev& t, const Bsdf& bsdf, const Frame& fr, V3 ng, V3 p, V3 wo, Rng& rng, BsdfSample& s PT_DBG_PARAMS) {
+PT_D bool guider_sample(const SdTreeDev& t, const Bsdf& bsdf, const Frame& fr, V3 ng, V3 p, V3 wo, Rng& rng, float* lds_scales, BsdfSample& s PT_DBG_PARAMS) {
     if (t.iteration == 0 || bsdf_is_specular(bsdf)) {
         const float u1d = rng_f32(rng), ua = rng_f32(rng), ub = rng_f32(rng);
         return bsdf_sample(bsdf, fr, ng, wo, u1d, ua, ub, true, s);
@@ -185,7 +190,7 @@ PT_D bool guider_sample(const SdTreeDev& t, const Bsdf& bsdf, const Frame& fr, V
         PT_TICK(5);
     }
     PT_TICK(4);
-    const float tree_pdf = dtree_pdf(t, leaf, sq);
+    const float tree_pdf = dtree_pdf(t, leaf, sq, lds_scales);
     PT_TICK(6);
     if (use_tree) {
         const float bp = bsdf_pdf(bsdf, fr, wo, s.wi) * 0.5f;
@@ -331,10 +336,12 @@ PT_D void store_vertex(const GuidedParams& gp, uint32_t row, uint32_t pid, V3 p,
 }
 
 // One iteration of PathGuidingIntegrator::random_walk's loop body (mod.rs:139-278).
-__global__ __launch_bounds__(kBlock, PT_SHADE_WAVES) void k_shade_guided(SceneDev sc, SdTreeDev tree, RenderParams rp, GuidedParams gp, PathCols in, HitCols hit, PathCols out,
+template <int KINDS>
+__global__ __launch_bounds__(kBlock, KINDS == 1 ? PT_GUIDED_DIFFUSE_WAVES : PT_SHADE_WAVES) void k_shade_guided(SceneDev sc, SdTreeDev tree, RenderParams rp, GuidedParams gp, PathCols in, HitCols hit, PathCols out,
                                                          ShadowCols sh, const RoundCounters* cur, RoundCounters* nxt) {
     __shared__ BlockAlloc sm_alloc;
     __shared__ uint32_t sm_count;
+    __shared__ float sm_scales[(kMaxQuadLevel + 1) * kBlock];
     PT_TICK_INIT();
     uint32_t n_shaded = 0, n_skipped = 0;
     const uint32_t n = cur->n_active;
@@ -385,7 +392,7 @@ __global__ __launch_bounds__(kBlock, PT_SHADE_WAVES) void k_shade_guided(SceneDe
                     flags &= ~FLAG_PASS_MASK;
                     const V3 wo = -d;
                     const V3 p = surf_p(sf);
-                    const Bsdf bsdf = make_bsdf(sc, material, wl);
+                    const Bsdf bsdf = make_bsdf<KINDS>(sc, material, wl);
                     const bool specular = bsdf_is_specular(bsdf);
                     const bool spec_bounce = (flags & FLAG_SPECULAR_BOUNCE) != 0;
                     Spec emitted = spec_splat(0.0f);
@@ -428,7 +435,7 @@ __global__ __launch_bounds__(kBlock, PT_SHADE_WAVES) void k_shade_guided(SceneDe
                     }
                     PT_TICK(2);
                     BsdfSample bs;
-                    const bool ok = guider_sample(tree, bsdf, sf.frame, sf.ng, p, wo, rng, bs PT_DBG_ARGS);
+                    const bool ok = guider_sample(tree, bsdf, sf.frame, sf.ng, p, wo, rng, sm_scales + threadIdx.x, bs PT_DBG_ARGS);
                     rp4.x = (uint32_t)rng.state;
                     rp4.y = (uint32_t)(rng.state >> 32);
                     if (!ok) {

@@ -221,6 +221,7 @@ __global__ __launch_bounds__(kBlock) void k_occluded_batch(SceneDev sc, const fl
 
 // ------------------------------------------------------------------ shade: `path` integrator
 // One iteration of PathIntegrator::li's loop body after the intersection (path_tracer.rs:69-180).
+template <int KINDS>
 __global__ __launch_bounds__(kBlock, PT_SHADE_WAVES) void k_shade_path(SceneDev sc, RenderParams rp, PathCols in, HitCols hit, PathCols out, ShadowCols sh,
                                                        const RoundCounters* cur, RoundCounters* nxt) {
     __shared__ BlockAlloc sm_alloc;
@@ -272,7 +273,7 @@ __global__ __launch_bounds__(kBlock, PT_SHADE_WAVES) void k_shade_path(SceneDev 
                     flags &= ~FLAG_PASS_MASK;
                     const V3 wo = -d;
                     const V3 p = surf_p(sf);
-                    const Bsdf bsdf = make_bsdf(sc, material, wl);
+                    const Bsdf bsdf = make_bsdf<KINDS>(sc, material, wl);
                     const bool spec_bounce = (flags & FLAG_SPECULAR_BOUNCE) != 0;
                     // emitted radiance of the surface that was hit (path_tracer.rs:82-108)
                     if (sf.tri.mesh < sc.n_emissive_meshes) {
@@ -467,6 +468,7 @@ __global__ __launch_bounds__(kBlock) void k_raygen_light(SceneDev sc, CameraDev 
 
 // LightPathIntegrator::random_walk loop body (light_path_tracer.rs:74-118). The depth counter counts loop
 // iterations (a pass-through surface burns one, unlike `path`).
+template <int KINDS>
 __global__ __launch_bounds__(kBlock, PT_SHADE_WAVES) void k_shade_light(SceneDev sc, CameraDev cam, RenderParams rp, PathCols in, HitCols hit, PathCols out, ShadowCols sh,
                                                         const RoundCounters* cur, RoundCounters* nxt) {
     __shared__ BlockAlloc sm_alloc;
@@ -502,7 +504,7 @@ __global__ __launch_bounds__(kBlock, PT_SHADE_WAVES) void k_shade_light(SceneDev
                 shaded = true;
                 const V3 wo = -d;
                 const V3 p = surf_p(sf);
-                const Bsdf bsdf = make_bsdf(sc, material, wl);
+                const Bsdf bsdf = make_bsdf<KINDS>(sc, material, wl);
                 CameraWi cw;
                 if (!bsdf_is_specular(bsdf) && camera_sample_wi(cam, p, cw)) {
                     Spec f = bsdf_eval(bsdf, sf.frame, sf.ng, wo, cw.wc, false) * spec_splat(cw.importance) * beta / cw.pdf;

@@ -110,6 +110,7 @@ struct ptgpu_ctx {
     std::vector<hipEvent_t> ev_pool;
     std::vector<int> ev_stage;  // stage of pair i (events 2i, 2i+1)
     bool census_on = false;
+    int kinds = 7;       // material kinds in use, rounded up to a compiled set (PT_LAUNCH_BY_KINDS)
     size_t bvh_lds = 0;  // dynamic LDS bytes of every kernel that walks the BVH (pt_device.h: bvh_intersect)
     DevBuf<unsigned long long> d_census;  // extend nodes, extend tris, occlude nodes, occlude tris
     double stage_ms[PTGPU_N_STAGES] = {0, 0, 0, 0, 0, 0};
@@ -119,6 +120,14 @@ struct ptgpu_ctx {
 };
 
 namespace {
+
+// Shade kernels are compiled for three material-kind sets: diffuse only (1), diffuse + dielectric (3), all (7).
+#define PT_LAUNCH_BY_KINDS(c, kernel, grid, ...)                                                                        \
+    do {                                                                                                                 \
+        if ((c)->kinds == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(kernel<1>), dim3(grid), dim3(kBlock), 0, (c)->stream, __VA_ARGS__);      \
+        else if ((c)->kinds == 3) hipLaunchKernelGGL(HIP_KERNEL_NAME(kernel<3>), dim3(grid), dim3(kBlock), 0, (c)->stream, __VA_ARGS__); \
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(kernel<7>), dim3(grid), dim3(kBlock), 0, (c)->stream, __VA_ARGS__);                      \
+    } while (0)
 
 int grid_for(const ptgpu_ctx* c, uint64_t n) {
     const uint64_t want = (n + kBlock - 1) / kBlock;
@@ -351,6 +360,12 @@ int ptgpu_scene_create(ptgpu_ctx* c, const ptgpu_scene_desc* desc) {
         if (m.kind < 0 || m.kind > 2) return fail(PTGPU_E_INVALID, "scene_create: unknown material kind");
         mats[i] = MaterialDev{m.kind, m.roughness, to_dev(m.s0, 0), to_dev(m.s1, 0)};
     }
+    {
+        int used = 0;
+        for (const MeshInfo& mi : mesh_info)
+            if (mi.material >= 0) used |= 1 << mats[mi.material].kind;
+        c->kinds = (used & (1 << MAT_CONDUCTOR)) ? 7 : ((used & (1 << MAT_DIELECTRIC)) ? 3 : 1);
+    }
     if (mats.empty()) mats.push_back(MaterialDev{0, 0.0f, SpectrumDev{0, 0, 0, 0, 0}, SpectrumDev{0, 0, 0, 0, 0}});
     if (emissions.empty()) emissions.push_back(SpectrumDev{0, 0, 0, 0, 1});
     if (emissive_leaf.empty()) emissive_leaf.push_back(0);
@@ -579,9 +594,9 @@ int run_batch_path_like(ptgpu_ctx* c, bool light, const RenderParams& rp, uint32
         {
             StageTimer t(c, PTGPU_STAGE_SHADE);
             if (light)
-                hipLaunchKernelGGL(k_shade_light, dim3(grid), dim3(kBlock), 0, c->stream, c->scene, c->camera, rp, A, H, B, S, cnt + round, cnt + round + 1);
+                PT_LAUNCH_BY_KINDS(c, k_shade_light, grid, c->scene, c->camera, rp, A, H, B, S, cnt + round, cnt + round + 1);
             else
-                hipLaunchKernelGGL(k_shade_path, dim3(grid), dim3(kBlock), 0, c->stream, c->scene, rp, A, H, B, S, cnt + round, cnt + round + 1);
+                PT_LAUNCH_BY_KINDS(c, k_shade_path, grid, c->scene, rp, A, H, B, S, cnt + round, cnt + round + 1);
         }
         {
             StageTimer t(c, PTGPU_STAGE_OCCLUDE);
