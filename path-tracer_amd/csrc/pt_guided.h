@@ -29,7 +29,9 @@ __device__ unsigned long long g_dbg_cycles[16];
 #endif
 
 struct GuidedState;  // host-side (ptgpu_guided_api.inc)
+struct GuidedPersist;
 void guided_free(GuidedState* g);
+void guided_persist_free(GuidedPersist* p);
 
 // Flat SD-tree in HBM (built by HostSdTree::flatten).
 //   snodes[i]    = {left, right, split_axis, leaf_id}; left == 0 <=> leaf

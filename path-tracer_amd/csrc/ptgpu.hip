@@ -34,10 +34,11 @@ const double kXyz[CIE_N][3] = {PT_CIE_XYZ_VALUES};
 template <class T>
 struct DevBuf {
     T* p = nullptr;
-    size_t n = 0;
+    size_t n = 0, cap = 0;
     hipError_t alloc(size_t count) {
         release();
         n = count;
+        cap = count;
         if (count == 0) return hipSuccess;
         return hipMalloc((void**)&p, count * sizeof(T));
     }
@@ -48,10 +49,32 @@ struct DevBuf {
         if (e != hipSuccess) return e;
         return hipStreamSynchronize(s);
     }
+    hipError_t reserve(size_t count) {  // grow-only alloc: contents are not preserved
+        if (count <= cap) {
+            n = count;
+            return hipSuccess;
+        }
+        return alloc(count);
+    }
+    // Re-used between guided waves: grows by half when too small, copies without waiting (the caller keeps `src`
+    // alive and synchronises the stream before touching it again).
+    hipError_t upload_async(const T* src, size_t count, hipStream_t s) {
+        if (count > cap) {
+            release();
+            const size_t want = count + count / 2 + 64;
+            hipError_t e = hipMalloc((void**)&p, want * sizeof(T));
+            if (e != hipSuccess) return e;
+            cap = want;
+        }
+        n = count;
+        if (count == 0) return hipSuccess;
+        return hipMemcpyAsync(p, src, count * sizeof(T), hipMemcpyHostToDevice, s);
+    }
     void release() {
         if (p) (void)hipFree(p);
         p = nullptr;
         n = 0;
+        cap = 0;
     }
     ~DevBuf() { release(); }
 };
@@ -117,6 +140,7 @@ struct ptgpu_ctx {
     uint64_t stage_launches[PTGPU_N_STAGES] = {0, 0, 0, 0, 0, 0};
     uint64_t launches = 0;
     GuidedState* guided = nullptr;
+    GuidedPersist* guided_persist = nullptr;
 };
 
 namespace {
@@ -254,6 +278,7 @@ void ptgpu_destroy(ptgpu_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     guided_free(c->guided);
+    guided_persist_free(c->guided_persist);
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;

@@ -172,7 +172,7 @@ bool HostSdTree::new_iteration(float directional_threshold, float spatial_thresh
 }
 
 void HostSdTree::flatten(SdTreeFlat& out) const {
-    out.snodes.assign(nodes.size(), make_uint4(0, 0, 0, 0));
+    out.snodes.resize(nodes.size());
     out.leaf_info.clear();
     out.leaf_snode.clear();
     // pass 1 (serial, cheap): leaf numbering and arena offsets

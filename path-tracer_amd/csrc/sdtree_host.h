@@ -7,9 +7,42 @@
 #include <string>
 #include <vector>
 
+#include <hip/hip_runtime_api.h>
+
+#include <new>
+
 #include "pt_types.h"
 
 namespace pt {
+
+// Page-locked host memory for everything that crosses PCIe between waves (the flattened tree going up, the collector
+// statistics coming down): pageable copies are staged by the runtime at a few GB/s, pinned ones run at link speed and
+// are truly asynchronous. Default construction is a no-op so that resize() does not zero-fill what flatten overwrites.
+template <class T>
+struct PinnedAlloc {
+    using value_type = T;
+    PinnedAlloc() = default;
+    template <class U>
+    PinnedAlloc(const PinnedAlloc<U>&) {}
+    T* allocate(size_t n) {
+        void* p = nullptr;
+        if (hipHostMalloc(&p, n * sizeof(T), hipHostMallocDefault) != hipSuccess) throw std::bad_alloc();
+        return static_cast<T*>(p);
+    }
+    void deallocate(T* p, size_t) { (void)hipHostFree(p); }
+    template <class U>
+    void construct(U*) noexcept {}
+    template <class U, class A, class... Rest>
+    void construct(U* p, A&& a, Rest&&... rest) {
+        ::new ((void*)p) U(static_cast<A&&>(a), static_cast<Rest&&>(rest)...);
+    }
+    template <class U>
+    bool operator==(const PinnedAlloc<U>&) const { return true; }
+    template <class U>
+    bool operator!=(const PinnedAlloc<U>&) const { return false; }
+};
+template <class T>
+using PinnedVec = std::vector<T, PinnedAlloc<T>>;
 
 struct HostDNode {  // DTreeNode (dtree.rs:28-32): 4 child sums + 4 child links (0 = leaf child)
     float rad[4] = {0, 0, 0, 0};
@@ -34,11 +67,11 @@ struct HostSNode {  // STreeNode (stree.rs:12-19)
 
 // Flat device image of the tree (see pt_guided.h for how the kernels read it).
 struct SdTreeFlat {
-    std::vector<uint4> snodes;          // {left, right, axis, leaf_id}
-    std::vector<uint4> leaf_info;       // per leaf: {sampler node offset, collector node offset, mean_is_zero, 0}
-    std::vector<float4> s_rad;          // sampler arena
-    std::vector<uint2> s_child;
-    std::vector<uint2> c_child;         // collector arena topology (sums start at zero on the device)
+    PinnedVec<uint4> snodes;            // {left, right, axis, leaf_id}
+    PinnedVec<uint4> leaf_info;         // per leaf: {sampler node offset, collector node offset, mean_is_zero, 0}
+    PinnedVec<float4> s_rad;            // sampler arena
+    PinnedVec<uint2> s_child;
+    PinnedVec<uint2> c_child;           // collector arena topology (sums start at zero on the device)
     std::vector<uint32_t> leaf_snode;   // leaf id -> STree node index
     uint32_t n_collector_nodes = 0;
 };
