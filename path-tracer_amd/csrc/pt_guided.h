@@ -43,6 +43,7 @@ void guided_persist_free(GuidedPersist* p);
 // ptgpu_guided_stats hands to the multi-GPU driver for its all-reduce.
 struct SdTreeDev {
     const uint4* snodes;
+    const uint32_t* top;  // jump table over the first kStreeTopLevels decisions (sdtree_host.h)
     const uint4* leaf_info;
     const float4* s_rad;
     const uint2* s_child;
@@ -72,10 +73,38 @@ PT_D V2 dir_to_square(V3 d) {  // path_guiding/mod.rs:412-421
 }
 
 // STree::leaf (stree.rs:202-229): halve along the node's axis until a leaf; also returns the leaf's box.
+// The first kStreeTopLevels halvings are done without touching the tree (axis = depth % 3, split at the midpoint:
+// the decisions are the reference's, bit for bit) and index a jump table; only deeper levels chase node links.
+template <bool WANT_BOX>
 PT_D uint32_t stree_leaf(const SdTreeDev& t, V3 p, V3& lo, V3& hi) {
     lo = t.blo;
     hi = t.bhi;
-    uint32_t ni = 0;
+    uint32_t code = 0;
+#pragma unroll
+    for (uint32_t d = 0; d < kStreeTopLevels; d++) {
+        const int ax = (int)(d % 3u);
+        const float mid = (get(lo, ax) + get(hi, ax)) / 2.0f;
+        const bool right = !(get(p, ax) < mid);
+        code = (code << 1) | (right ? 1u : 0u);
+        if (right) set(lo, ax, mid);
+        else set(hi, ax, mid);
+    }
+    const uint32_t entry = t.top[code];
+    if (entry & 0x80000000u) {
+        if (WANT_BOX) {  // the leaf sits above the table's depth: redo its (fewer) halvings for the box
+            const uint32_t depth = entry & 15u;
+            lo = t.blo;
+            hi = t.bhi;
+            for (uint32_t d = 0; d < depth; d++) {
+                const int ax = (int)(d % 3u);
+                const float mid = (get(lo, ax) + get(hi, ax)) / 2.0f;
+                if (get(p, ax) < mid) set(hi, ax, mid);
+                else set(lo, ax, mid);
+            }
+        }
+        return (entry >> 4) & 0x7ffffffu;
+    }
+    uint32_t ni = entry >> 4;
     for (int guard = 0; guard < 128; guard++) {
         const uint4 n = t.snodes[ni];
         if (n.x == 0) return n.w;
@@ -175,7 +204,7 @@ PT_D bool guider_sample(const SdTreeDev& t, const Bsdf& bsdf, const Frame& fr, V
         return bsdf_sample(bsdf, fr, ng, wo, u1d, ua, ub, true, s);
     }
     V3 lo, hi;
-    const uint4 leaf = t.leaf_info[stree_leaf(t, p, lo, hi)];
+    const uint4 leaf = t.leaf_info[stree_leaf<false>(t, p, lo, hi)];
     PT_TICK(3);
     // Both branches need the tree's pdf at the chosen direction; the quadtree descent is hoisted out of the branch
     // so a wave walks it once with all lanes instead of twice with half of them. Values are unchanged.
@@ -259,12 +288,12 @@ PT_D void dtree_record_box(const SdTreeDev& t, uint32_t leaf_id, uint4 leaf, V2 
 PT_D void stree_record_jittered(const SdTreeDev& t, V3 p, V3 wi, float radiance, float u0, float u1, float u2) {
     const V2 p2 = dir_to_square(wi);
     V3 lo, hi;
-    (void)stree_leaf(t, p, lo, hi);
+    (void)stree_leaf<true>(t, p, lo, hi);
     const V3 ext = hi - lo;
     const V3 jlo = p - ext / 2.0f;  // Bounds3::around(p, extent)
     const V3 jhi = p + ext / 2.0f;
     const V3 q = clamp3(jlo + mk3(u0, u1, u2) * (jhi - jlo), t.blo, t.bhi);
-    const uint32_t leaf_id = stree_leaf(t, q, lo, hi);
+    const uint32_t leaf_id = stree_leaf<false>(t, q, lo, hi);
     dtree_record_box(t, leaf_id, t.leaf_info[leaf_id], p2, radiance);
 }
 

@@ -192,6 +192,28 @@ void HostSdTree::flatten(SdTreeFlat& out) const {
         s_total += n.sampler.nodes.size();
         c_total += n.collector.nodes.size();
     }
+    // top-of-tree jump table (leaf ids are known now)
+    out.top.resize((size_t)1 << kStreeTopLevels);
+    {
+        struct Item {
+            uint32_t node, prefix, depth;
+        };
+        std::vector<Item> todo{{0u, 0u, 0u}};
+        while (!todo.empty()) {
+            const Item it = todo.back();
+            todo.pop_back();
+            const HostSNode& n = nodes[it.node];
+            if (n.left != 0 && it.depth < kStreeTopLevels) {
+                todo.push_back({n.left, it.prefix << 1, it.depth + 1});
+                todo.push_back({n.right, (it.prefix << 1) | 1u, it.depth + 1});
+                continue;
+            }
+            const uint32_t entry = n.left == 0 ? (0x80000000u | (out.snodes[it.node].w << 4) | it.depth) : ((it.node << 4) | it.depth);
+            const uint32_t span = 1u << (kStreeTopLevels - it.depth);
+            const uint32_t first = it.prefix << (kStreeTopLevels - it.depth);
+            for (uint32_t k = 0; k < span; k++) out.top[first + k] = entry;
+        }
+    }
     out.s_rad.resize(s_total);
     out.s_child.resize(s_total);
     out.c_child.resize(c_total);

@@ -68,6 +68,7 @@ struct HostSNode {  // STreeNode (stree.rs:12-19)
 // Flat device image of the tree (see pt_guided.h for how the kernels read it).
 struct SdTreeFlat {
     PinnedVec<uint4> snodes;            // {left, right, axis, leaf_id}
+    PinnedVec<uint32_t> top;            // kStreeTopLevels-bit descent code -> packed node / leaf (pt_guided.h: stree_leaf)
     PinnedVec<uint4> leaf_info;         // per leaf: {sampler node offset, collector node offset, mean_is_zero, 0}
     PinnedVec<float4> s_rad;            // sampler arena
     PinnedVec<uint2> s_child;
@@ -75,6 +76,12 @@ struct SdTreeFlat {
     std::vector<uint32_t> leaf_snode;   // leaf id -> STree node index
     uint32_t n_collector_nodes = 0;
 };
+
+// The spatial tree always halves its box at the midpoint and cycles the axes with the depth (stree.rs:55-101), so
+// the first kStreeTopLevels left/right decisions of a descent depend on the point and the root box only. The device
+// computes them in registers and jumps to the node they lead to through this table: entry = depth | payload << 4 |
+// is_leaf << 31, payload = leaf id for a leaf reached at depth <= kStreeTopLevels, else the node index at that depth.
+// (kStreeTopLevels lives in pt_types.h: host and device share it)
 
 struct HostSdTree {
     std::vector<HostSNode> nodes;
