@@ -25,7 +25,7 @@ __device__ unsigned long long g_dbg_cycles[16];
 #endif
 
 #ifndef PT_GUIDED_DIFFUSE_WAVES
-#define PT_GUIDED_DIFFUSE_WAVES 2
+#define PT_GUIDED_DIFFUSE_WAVES 3
 #endif
 
 struct GuidedState;  // host-side (ptgpu_guided_api.inc)
@@ -368,7 +368,7 @@ PT_D void store_vertex(const GuidedParams& gp, uint32_t row, uint32_t pid, V3 p,
 
 // One iteration of PathGuidingIntegrator::random_walk's loop body (mod.rs:139-278).
 template <int KINDS>
-__global__ __launch_bounds__(kBlock, KINDS == 1 ? PT_GUIDED_DIFFUSE_WAVES : PT_SHADE_WAVES) void k_shade_guided(SceneDev sc, SdTreeDev tree, RenderParams rp, GuidedParams gp, PathCols in, HitCols hit, PathCols out,
+__global__ __launch_bounds__(kBlock, KINDS != 7 ? PT_GUIDED_DIFFUSE_WAVES : PT_SHADE_WAVES) void k_shade_guided(SceneDev sc, SdTreeDev tree, RenderParams rp, GuidedParams gp, PathCols in, HitCols hit, PathCols out,
                                                          ShadowCols sh, const RoundCounters* cur, RoundCounters* nxt) {
     __shared__ BlockAlloc sm_alloc;
     __shared__ uint32_t sm_count;
