@@ -488,7 +488,9 @@ PT_HD float fresnel_dielectric(float cos_i, float eta) {  // bsdfs.rs:316-331
     float r_perp = (cos_i - eta * cos_t) / (cos_i + eta * cos_t);
     return (r_parl * r_parl + r_perp * r_perp) / 2.0f;
 }
-PT_D float fresnel_complex(float cos_i, Cx eta) {  // bsdfs.rs:333-343
+// Not inlined: eight wavelengths times several call sites of this (complex sqrt inside) made the all-materials shade
+// kernels 100-180 KB, far beyond the 64 KB instruction cache two CUs share.
+__device__ __attribute__((noinline)) float fresnel_complex(float cos_i, Cx eta) {  // bsdfs.rs:333-343
     cos_i = clampf(cos_i, 0.0f, 1.0f);
     float s2i = 1.0f - cos_i * cos_i;
     Cx s2t = cx_div(Cx{s2i, 0.0f}, cx_mul(eta, eta));
