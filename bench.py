@@ -165,6 +165,16 @@ def main() -> int:
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
                 "avg_launch_ms": round(avg_ms, 4), "launches": launches, "alg_bytes_per_launch": int(alg_bytes / launches),
                 "stage_ms_per_step": {k: round(stage_ms[k] / args.steps, 2) for k in stage_ms if stage_n[k]}}
+    # HBM-side bytes per launch of the same kernel on the same workload, from the committed rocprofv3 --pmc passes
+    # (tools/gpu_traffic.sh: FETCH_SIZE x2 + WRITE_SIZE, MI355X_MICROARCH.md "HBM"); counters cannot be read in-process.
+    if args.workload == "guided" and not args.spp:
+        cands = sorted((REPO / "profiles").glob("*_guided_traffic.json"))
+        if cands:
+            tj = json.loads(cands[-1].read_text())
+            for kname, d in tj.get("kernels", {}).items():
+                if roofline["kernel"] in kname:
+                    roofline["traffic"] = int(d["hbm_bytes_per_launch"])
+                    roofline["traffic_source"] = f"profiles/{cands[-1].name}"
     if census:
         roofline["census"] = {"nodes_per_extend_ray": round(census["extend_nodes"] / max(1, st["extend_rays"]), 2),
                               "tris_per_extend_ray": round(census["extend_tris"] / max(1, st["extend_rays"]), 2),
