@@ -31,6 +31,7 @@ WORKLOADS = {
     "path": ("cornell-box", "path", 512, 512, 64, 8),                  # configs[0]
     "veach-mis": ("veach-mis", "path", 1280, 720, 1024, 3),            # configs[1]
     "lightpath": ("cornell-box", "lightpath", 512, 512, 512, 16),      # configs[2]
+    "guided-large": ("veach-mis", "guided", 1280, 720, 512, 32),       # configs[4]: largest shipped scene, 4096 spp over 8 GPUs
 }
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
@@ -186,7 +187,7 @@ def main() -> int:
     if world == 1 and not args.no_cpu_baseline:
         import oracle_bind as ob
         cores = min(16, os.cpu_count() or 1)
-        cpu_spp = {"guided": 15, "path": 8, "veach-mis": 8, "lightpath": 8}[args.workload]
+        cpu_spp = {"guided": 15, "path": 8, "veach-mis": 8, "lightpath": 8, "guided-large": 3}[args.workload]
         o = ob.OracleScene(sc)
         t0 = time.perf_counter()
         _, _, cst = o.render(sc.camera, integ, cpu_spp, n_threads=cores)
