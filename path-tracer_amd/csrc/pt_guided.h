@@ -621,9 +621,10 @@ __global__ __launch_bounds__(kBlock) void k_guide_scan(SceneDev sc, RenderParams
                 }
             }
         }
-        if (valid && gp.write_film) {
-            const Lambdas wl = load_lambdas(rp.lambda_tab, rp4.w & 0xffffu, true);
-            film_add(sc, rp.film, rp4.z, l, wl, (flags & FLAG_SECONDARY_TERMINATED) != 0);
+        if (gp.write_film) {
+            Lambdas wl;
+            if (valid) wl = load_lambdas(rp.lambda_tab, rp4.w & 0xffffu, true);
+            film_add_wave(sc, rp.film, rp4.z, l, wl, (flags & FLAG_SECONDARY_TERMINATED) != 0, valid);
         }
         __syncthreads();
         if (threadIdx.x == 0) rq.count[chunk] = sm_n;

@@ -13,3 +13,4 @@ def run(name, spp, **ov):
 run("cornell-box-guided", 512)
 run("cornell-box", 64, max_depth=8)
 run("veach-mis", 64, resx=1280, resy=720)
+run("cornell-box", 128, integrator="lightpath")
