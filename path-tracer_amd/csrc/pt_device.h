@@ -663,10 +663,13 @@ PT_D float bsdf_pdf(const Bsdf& m, const Frame& fr, V3 wo, V3 wi) { return bsdf_
 struct Tri {
     V3 p0, p1, p2;
     uint32_t mesh;
+    uint32_t tag;  // material + 1 (0 = pass-through) | has_normals << 31
 };
+PT_HD int tri_material(const Tri& t) { return (int)(t.tag & 0x7fffffffu) - 1; }
+PT_HD bool tri_has_normals(const Tri& t) { return (t.tag & 0x80000000u) != 0; }
 PT_D Tri load_tri(const SceneDev& sc, uint32_t k) {
     const float4 a = sc.tri_v[3 * k], b = sc.tri_v[3 * k + 1], c = sc.tri_v[3 * k + 2];
-    return Tri{mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), f2u(a.w)};
+    return Tri{mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), f2u(a.w), f2u(c.w)};
 }
 struct Surface {  // SceneInteraction (scene.rs:65-86,192-217)
     V3 blo, bhi;   // error box around p
@@ -684,7 +687,7 @@ PT_D Surface make_surface(const SceneDev& sc, uint32_t prim, float b0, float b1,
     V3 err = gamma_n(7.0f) * abs_sum;
     s.ng = tri_normal(s.tri.p0, s.tri.p1, s.tri.p2);
     V3 ns = s.ng;
-    if (sc.mesh_info[s.tri.mesh].has_normals) {
+    if (tri_has_normals(s.tri)) {
         const float4 n0 = sc.tri_n[3 * prim], n1 = sc.tri_n[3 * prim + 1], n2 = sc.tri_n[3 * prim + 2];
         ns = normalize((mk3(n0.x, n0.y, n0.z) * b0) + (mk3(n1.x, n1.y, n1.z) * b1) + (mk3(n2.x, n2.y, n2.z) * b2));
     }
@@ -737,7 +740,8 @@ PT_D bool choose_light(const SceneDev& sc, float u, Tri& t, float& pmf) {
     if (sc.n_emissive_tris == 0) return false;
     uint32_t idx = (uint32_t)((float)sc.n_emissive_tris * u);
     if (idx >= sc.n_emissive_tris) idx = sc.n_emissive_tris - 1;
-    t = load_tri(sc, sc.emissive_tris[idx]);
+    const float4 a = sc.light_v[3 * idx], b = sc.light_v[3 * idx + 1], c = sc.light_v[3 * idx + 2];
+    t = Tri{mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), f2u(a.w), f2u(c.w)};
     pmf = 1.0f / (float)sc.n_emissive_tris;
     return true;
 }

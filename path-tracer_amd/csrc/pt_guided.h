@@ -92,7 +92,7 @@ PT_D uint32_t stree_leaf(const SdTreeDev& t, V3 p, V3& lo, V3& hi) {
     const uint32_t entry = t.top[code];
     if (entry & 0x80000000u) {
         if (WANT_BOX) {  // the leaf sits above the table's depth: redo its (fewer) halvings for the box
-            const uint32_t depth = entry & 15u;
+            const uint32_t depth = entry & 31u;
             lo = t.blo;
             hi = t.bhi;
             for (uint32_t d = 0; d < depth; d++) {
@@ -102,9 +102,9 @@ PT_D uint32_t stree_leaf(const SdTreeDev& t, V3 p, V3& lo, V3& hi) {
                 else set(lo, ax, mid);
             }
         }
-        return (entry >> 4) & 0x7ffffffu;
+        return (entry >> 5) & 0x3ffffffu;
     }
-    uint32_t ni = entry >> 4;
+    uint32_t ni = entry >> 5;
     for (int guard = 0; guard < 128; guard++) {
         const uint4 n = t.snodes[ni];
         if (n.x == 0) return n.w;
@@ -411,7 +411,7 @@ __global__ __launch_bounds__(kBlock, KINDS != 7 ? PT_GUIDED_DIFFUSE_WAVES : PT_S
                 beta = load_spec(in.beta0, in.beta1, i);
                 const Lambdas wl = load_lambdas(rp.lambda_tab, rp4.w & 0xffffu, false);
                 const Surface sf = make_surface(sc, prim, tb.y, tb.z, tb.w);
-                const int material = sc.mesh_info[sf.tri.mesh].material;
+                const int material = tri_material(sf.tri);
                 uint32_t depth = flags & FLAG_DEPTH_MASK;
                 if (material < 0) {
                     // pass-through: no bounce counted and, unlike `path`, specular_bounce is left alone (mod.rs:153-156)

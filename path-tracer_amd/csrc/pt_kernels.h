@@ -277,7 +277,7 @@ __global__ __launch_bounds__(kBlock, PT_SHADE_WAVES) void k_shade_path(SceneDev 
                 pid = f2u(pp.w);
                 beta = load_spec(in.beta0, in.beta1, i);
                 const Surface sf = make_surface(sc, prim, tb.y, tb.z, tb.w);
-                const int material = sc.mesh_info[sf.tri.mesh].material;
+                const int material = tri_material(sf.tri);
                 uint32_t depth = flags & FLAG_DEPTH_MASK;
                 if (material < 0) {
                     // no BSDF: continue straight on, do not count a bounce (path_tracer.rs:76-80)
@@ -521,7 +521,7 @@ __global__ __launch_bounds__(kBlock, PT_SHADE_WAVES) void k_shade_light(SceneDev
             const float4 tb = hit.tb[i];
             const Lambdas wl = load_lambdas(rp.lambda_tab, rp4.w, true);
             const Surface sf = make_surface(sc, hit.prim[i], tb.y, tb.z, tb.w);
-            const int material = sc.mesh_info[sf.tri.mesh].material;
+            const int material = tri_material(sf.tri);
             uint32_t depth = (flags & FLAG_DEPTH_MASK) + 1;  // iterations consumed including this one
             if (material < 0) {
                 o = offset_ray_origin(sf.blo, sf.bhi, sf.ng, d);

@@ -12,7 +12,7 @@ constexpr int kBlock = 256;     // threads per workgroup of every kernel
 #define PT_LEAF_QUEUE 4
 #endif
 constexpr uint32_t kLeafQueue = PT_LEAF_QUEUE;  // leaves a ray collects before testing their triangles (pt_device.h)
-constexpr uint32_t kStreeTopLevels = 15;  // guided: levels of the spatial tree resolved through the jump table
+constexpr uint32_t kStreeTopLevels = 18;  // guided: levels of the spatial tree resolved through the jump table
 constexpr int kBvhStack = 64;   // ArrayVec<usize, 64> (pt/src/bvh.rs:94)
 
 enum { MAT_LAMBERTIAN = 0, MAT_DIELECTRIC = 1, MAT_CONDUCTOR = 2 };
@@ -40,6 +40,7 @@ struct SceneDev {
     const float4* tri_v;
     const float4* tri_n;
     const MeshInfo* mesh_info;
+    const float4* light_v;             // the emissive triangles' tri_v records again, in emissive_tris order (one hop less for NEE)
     const MaterialDev* materials;
     const SpectrumDev* emissions;      // per emissive mesh (mesh_index < n_emissive_meshes <=> emitter)
     const uint32_t* emissive_tris;     // leaf-order index of every emissive triangle, in Scene::emissive_triangles order

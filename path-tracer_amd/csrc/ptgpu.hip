@@ -108,6 +108,7 @@ struct ptgpu_ctx {
     CameraDev camera{};
     DevBuf<float4> d_nodes, d_tri_v, d_tri_n;
     DevBuf<MeshInfo> d_mesh_info;
+    DevBuf<float4> d_light_v;
     DevBuf<MaterialDev> d_materials;
     DevBuf<SpectrumDev> d_emissions;
     DevBuf<uint32_t> d_emissive;
@@ -363,7 +364,9 @@ int ptgpu_scene_create(ptgpu_ctx* c, const ptgpu_scene_desc* desc) {
         const uint32_t m = tri_mesh[id], t = tri_index[id];
         const ptgpu_mesh& mesh = desc->meshes[order[m]];
         const uint32_t idx[3] = {mesh.triangles[3 * t], mesh.triangles[3 * t + 1], mesh.triangles[3 * t + 2]};
-        const uint32_t tag[3] = {m, t, 0};
+        // third tag: material + 1 (0 = pass-through surface) | has_normals << 31, so that shading a hit needs no
+        // dependent mesh_info load after the triangle fetch
+        const uint32_t tag[3] = {m, t, (uint32_t)(mesh_info[m].material + 1) | (mesh.normals ? 0x80000000u : 0u)};
         for (int v = 0; v < 3; v++) {
             const float* p = mesh.points + 3 * (size_t)idx[v];
             tri_v[3 * k + v] = make_float4(p[0], p[1], p[2], u2f(tag[v]));
@@ -399,6 +402,12 @@ int ptgpu_scene_create(ptgpu_ctx* c, const ptgpu_scene_desc* desc) {
     HIP_TRY(c->d_tri_v.upload(tri_v, c->stream));
     HIP_TRY(c->d_tri_n.upload(tri_n, c->stream));
     HIP_TRY(c->d_mesh_info.upload(mesh_info, c->stream));
+    {
+        std::vector<float4> light_v(3 * emissive_leaf.size());
+        for (size_t i = 0; i < emissive_leaf.size(); i++)
+            for (int v = 0; v < 3; v++) light_v[3 * i + v] = tri_v[3 * (size_t)emissive_leaf[i] + v];
+        HIP_TRY(c->d_light_v.upload(light_v, c->stream));
+    }
     HIP_TRY(c->d_materials.upload(mats, c->stream));
     HIP_TRY(c->d_emissions.upload(emissions, c->stream));
     HIP_TRY(c->d_emissive.upload(emissive_leaf, c->stream));
@@ -407,6 +416,7 @@ int ptgpu_scene_create(ptgpu_ctx* c, const ptgpu_scene_desc* desc) {
     s.tri_v = c->d_tri_v.p;
     s.tri_n = c->d_tri_n.p;
     s.mesh_info = c->d_mesh_info.p;
+    s.light_v = c->d_light_v.p;
     s.materials = c->d_materials.p;
     s.emissions = c->d_emissions.p;
     s.emissive_tris = c->d_emissive.p;

@@ -208,7 +208,7 @@ void HostSdTree::flatten(SdTreeFlat& out) const {
                 todo.push_back({n.right, (it.prefix << 1) | 1u, it.depth + 1});
                 continue;
             }
-            const uint32_t entry = n.left == 0 ? (0x80000000u | (out.snodes[it.node].w << 4) | it.depth) : ((it.node << 4) | it.depth);
+            const uint32_t entry = n.left == 0 ? (0x80000000u | (out.snodes[it.node].w << 5) | it.depth) : ((it.node << 5) | it.depth);
             const uint32_t span = 1u << (kStreeTopLevels - it.depth);
             const uint32_t first = it.prefix << (kStreeTopLevels - it.depth);
             for (uint32_t k = 0; k < span; k++) out.top[first + k] = entry;

@@ -79,7 +79,7 @@ struct SdTreeFlat {
 
 // The spatial tree always halves its box at the midpoint and cycles the axes with the depth (stree.rs:55-101), so
 // the first kStreeTopLevels left/right decisions of a descent depend on the point and the root box only. The device
-// computes them in registers and jumps to the node they lead to through this table: entry = depth | payload << 4 |
+// computes them in registers and jumps to the node they lead to through this table: entry = depth | payload << 5 |
 // is_leaf << 31, payload = leaf id for a leaf reached at depth <= kStreeTopLevels, else the node index at that depth.
 // (kStreeTopLevels lives in pt_types.h: host and device share it)
 
