@@ -197,6 +197,66 @@ PT_D float dtree_pdf(const SdTreeDev& t, uint4 leaf, V2 p, float* scales) {
     return result * kInvFourPi;
 }
 
+// One descent that serves both halves of Guider::sample: lanes with `sample` set draw a direction (DTree::sample),
+// the others look up the pdf of the direction they bring in `sq` (DTree::pdf). A sampled point lies in the cell it
+// was drawn from, so DTree::pdf of it would visit the very nodes the sampling descent visited and multiply the same
+// factors: the sampling lanes collect them on the way down instead of descending a second time. The rare cases where
+// that argument does not hold (the point was pushed out of its cell by the epsilon/clamp adjustments, or a child of
+// zero weight was drawn) fall back to the separate pdf descent. Returns the tree pdf; `sq` is an output for sampling lanes.
+PT_D float dtree_walk(const SdTreeDev& t, uint4 leaf, bool sample, Rng& rng, V2& sq, float* scales) {
+    if (leaf.z) {
+        if (sample) {
+            const float a = rng_f32(rng), b = rng_f32(rng);
+            sq = V2{a, b};
+        }
+        return kInvFourPi;
+    }
+    int n = 0;
+    uint32_t ni = 0;
+    Cell cell{0, 0, 0};
+    float result;
+    bool redo = false;
+    for (;;) {
+        const float4 r = t.s_rad[leaf.x + ni];
+        const uint2 links = t.s_child[leaf.x + ni];
+        int c;
+        Cell child;
+        if (sample) {
+            c = sample_discrete4(rng_f32(rng), r.x, r.y, r.z, r.w);
+            child = Cell{2 * cell.ix + (uint32_t)(c & 1), 2 * cell.iy + (uint32_t)(c >> 1), cell.level + 1};
+        } else {
+            c = cell_child_of(cell, sq, child);
+        }
+        const float rc = comp4(r, c);
+        if (rc == 0.0f) {
+            if (!sample) {
+                result = 0.0f;
+                break;
+            }
+            redo = true;  // DTree::pdf would stop here; DTree::sample goes on
+        }
+        const float scale = 4.0f * rc / ((((0.0f + r.x) + r.y) + r.z) + r.w);
+        const uint32_t link = child_link(links, c);
+        cell = child;
+        if (link == 0 || child.level >= kMaxQuadLevel) {
+            result = scale;
+            break;
+        }
+        scales[(n++) * kBlock] = scale;
+        ni = link;
+    }
+    if (sample) {
+        const float a = rng_f32(rng), b = rng_f32(rng);
+        const Box2 cb = cell_box(cell);
+        V2 s = cb.lo + V2{a, b} * box2_extent(cb);
+        s = min2(s, cb.hi - V2{kEps, kEps});
+        sq = clamp2(s, V2{0.0f, 0.0f}, V2{1.0f, 1.0f});
+        if (redo || !(sq.x >= cb.lo.x && sq.x < cb.hi.x && sq.y >= cb.lo.y && sq.y < cb.hi.y)) return dtree_pdf(t, leaf, sq, scales);
+    }
+    for (int i = n - 1; i >= 0; i--) result = scales[i * kBlock] * result;  // innermost first, as the recursion multiplies
+    return result * kInvFourPi;
+}
+
 // Guider::sample (path_guiding/mod.rs:315-368).
 PT_D bool guider_sample(const SdTreeDev& t, const Bsdf& bsdf, const Frame& fr, V3 ng, V3 p, V3 wo, Rng& rng, float* lds_scales, BsdfSample& s PT_DBG_PARAMS) {
     if (t.iteration == 0 || bsdf_is_specular(bsdf)) {
@@ -206,24 +266,21 @@ PT_D bool guider_sample(const SdTreeDev& t, const Bsdf& bsdf, const Frame& fr, V
     V3 lo, hi;
     const uint4 leaf = t.leaf_info[stree_leaf<false>(t, p, lo, hi)];
     PT_TICK(3);
-    // Both branches need the tree's pdf at the chosen direction; the quadtree descent is hoisted out of the branch
-    // so a wave walks it once with all lanes instead of twice with half of them. Values are unchanged.
+    // Both branches need the tree's pdf at the chosen direction: one quadtree descent per wave serves the lanes
+    // that sample from the tree and the lanes that only evaluate it (dtree_walk). Values are unchanged.
     const bool use_tree = rng_f32(rng) < 0.5f;
-    V2 sq;
-    if (use_tree) {
-        sq = dtree_sample(t, leaf, rng);
-        s.wi = square_to_dir(sq);
-        PT_TICK(4);
-    } else {
+    V2 sq = V2{0.0f, 0.0f};
+    if (!use_tree) {
         const float u1d = rng_f32(rng), ua = rng_f32(rng), ub = rng_f32(rng);
         if (!bsdf_sample(bsdf, fr, ng, wo, u1d, ua, ub, true, s)) return false;
         sq = dir_to_square(s.wi);
         PT_TICK(5);
     }
     PT_TICK(4);
-    const float tree_pdf = dtree_pdf(t, leaf, sq, lds_scales);
+    const float tree_pdf = dtree_walk(t, leaf, use_tree, rng, sq, lds_scales);
     PT_TICK(6);
     if (use_tree) {
+        s.wi = square_to_dir(sq);
         const float bp = bsdf_pdf(bsdf, fr, wo, s.wi) * 0.5f;
         if (bp == 0.0f) return false;  // the tree proposed a direction the BSDF cannot produce: the walk ends here
         s.pdf = bp + tree_pdf * 0.5f;
