@@ -698,8 +698,17 @@ PT_D Surface make_surface(const SceneDev& sc, uint32_t prim, float b0, float b1,
 }
 // KINDS = bit mask of the material kinds the scene uses (1 << MAT_*), fixed at scene creation. The shade kernels are
 // compiled per mask so that a scene without, say, conductors does not carry their registers and branches.
+// (spec_lookup: see SpecTab in pt_types.h.)
+PT_D Spec spec_lookup(const SpecTab& st, uint32_t spectrum, uint32_t row) {
+    const float4* e = st.tab + 2 * ((size_t)spectrum * st.n_rows + row);
+    const float4 a = e[0], b = e[1];
+    Spec s;
+    s.v[0] = a.x; s.v[1] = a.y; s.v[2] = a.z; s.v[3] = a.w;
+    s.v[4] = b.x; s.v[5] = b.y; s.v[6] = b.z; s.v[7] = b.w;
+    return s;
+}
 template <int KINDS>
-PT_D Bsdf make_bsdf(const SceneDev& sc, int material, const Lambdas& wl) {
+PT_D Bsdf make_bsdf(const SceneDev& sc, const SpecTab& st, int material, uint32_t row) {
     const MaterialDev m = sc.materials[material];
     Bsdf b;
     b.kind = m.kind;
@@ -710,16 +719,16 @@ PT_D Bsdf make_bsdf(const SceneDev& sc, int material, const Lambdas& wl) {
     else if (!(KINDS & (1 << MAT_DIELECTRIC))) b.kind = m.kind == MAT_LAMBERTIAN ? MAT_LAMBERTIAN : MAT_CONDUCTOR;
     else if (!(KINDS & (1 << MAT_LAMBERTIAN))) b.kind = m.kind == MAT_DIELECTRIC ? MAT_DIELECTRIC : MAT_CONDUCTOR;
     b.roughness = m.roughness;
-    b.a = spectrum_eval(m.s0, wl, sc.d65);
-    b.b = (b.kind == MAT_CONDUCTOR) ? spectrum_eval(m.s1, wl, sc.d65) : spec_splat(0.0f);
+    b.a = spec_lookup(st, 2u * (uint32_t)material, row);
+    b.b = (b.kind == MAT_CONDUCTOR) ? spec_lookup(st, 2u * (uint32_t)material + 1u, row) : spec_splat(0.0f);
     return b;
 }
 
 // ------------------------------------------------------------------ area lights (pt/src/lighting.rs:12-169)
 // AreaLight::emitted: one-sided along the geometric normal.
-PT_D Spec light_emitted(const SceneDev& sc, const Tri& t, V3 n, V3 from, V3 to, const Lambdas& wl) {
+PT_D Spec light_emitted(const SpecTab& st, const Tri& t, V3 n, V3 from, V3 to, uint32_t row) {
     if (dot(to - from, n) <= 0.0f) return spec_splat(0.0f);
-    return spectrum_eval(sc.emissions[t.mesh], wl, sc.d65);
+    return spec_lookup(st, st.emission_base + t.mesh, row);
 }
 PT_HD float light_pdf_li(const Tri& t, V3 n, V3 from, V3 to) {  // pdf_li_solid_angle
     float area_pdf = 1.0f / tri_area(t.p0, t.p1, t.p2);

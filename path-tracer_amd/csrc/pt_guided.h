@@ -466,7 +466,7 @@ __global__ __launch_bounds__(kBlock, KINDS != 7 ? PT_GUIDED_DIFFUSE_WAVES : PT_S
             } else {
                 const float4 tb = hit.tb[i];
                 beta = load_spec(in.beta0, in.beta1, i);
-                const Lambdas wl = load_lambdas(rp.lambda_tab, rp4.w & 0xffffu, false);
+                const uint32_t row = rp4.w & 0xffffu;  // wavelength-table row of this path
                 const Surface sf = make_surface(sc, prim, tb.y, tb.z, tb.w);
                 const int material = tri_material(sf.tri);
                 uint32_t depth = flags & FLAG_DEPTH_MASK;
@@ -480,18 +480,18 @@ __global__ __launch_bounds__(kBlock, KINDS != 7 ? PT_GUIDED_DIFFUSE_WAVES : PT_S
                     flags &= ~FLAG_PASS_MASK;
                     const V3 wo = -d;
                     const V3 p = surf_p(sf);
-                    const Bsdf bsdf = make_bsdf<KINDS>(sc, material, wl);
+                    const Bsdf bsdf = make_bsdf<KINDS>(sc, rp.spec, material, row);
                     const bool specular = bsdf_is_specular(bsdf);
                     const bool spec_bounce = (flags & FLAG_SPECULAR_BOUNCE) != 0;
                     Spec emitted = spec_splat(0.0f);
                     if (sf.tri.mesh < sc.n_emissive_meshes) {
                         const bool direct = (depth == 0) || spec_bounce;
-                        if (rp.mode == MODE_PT || direct) emitted = light_emitted(sc, sf.tri, sf.ng, p, o, wl);
+                        if (rp.mode == MODE_PT || direct) emitted = light_emitted(rp.spec, sf.tri, sf.ng, p, o, row);
                         else if (rp.mode == MODE_MIS) {
                             const float pb = prev_pdf;
                             const float pl = light_pdf_li(sf.tri, sf.ng, prev_p, p);
                             const float w = (pb * pb) / (pb * pb + pl * pl);
-                            emitted = w * light_emitted(sc, sf.tri, sf.ng, p, o, wl);
+                            emitted = w * light_emitted(rp.spec, sf.tri, sf.ng, p, o, row);
                         }
                     }
                     Rng rng{(uint64_t)rp4.x | ((uint64_t)rp4.y << 32), rng_inc_for_pixel(rp4.z % rp.resx, rp4.z / rp.resx)};
@@ -506,7 +506,7 @@ __global__ __launch_bounds__(kBlock, KINDS != 7 ? PT_GUIDED_DIFFUSE_WAVES : PT_S
                             Spec f = bsdf_eval(bsdf, sf.frame, sf.ng, wo, ls.wl, true) / (ls.pdf * pmf);
                             if (!spec_is_black(f)) {
                                 const V3 lp = (ls.blo + ls.bhi) / 2.0f;
-                                const Spec le = spectrum_eval(sc.emissions[lt.mesh], wl, sc.d65);
+                                const Spec le = spec_lookup(rp.spec, rp.spec.emission_base + lt.mesh, row);
                                 if (rp.mode == MODE_NEE) contrib = f * le;
                                 else {
                                     const float pl = ls.pdf;
@@ -678,11 +678,7 @@ __global__ __launch_bounds__(kBlock) void k_guide_scan(SceneDev sc, RenderParams
                 }
             }
         }
-        if (gp.write_film) {
-            Lambdas wl;
-            if (valid) wl = load_lambdas(rp.lambda_tab, rp4.w & 0xffffu, true);
-            film_add_wave(sc, rp.film, rp4.z, l, wl, (flags & FLAG_SECONDARY_TERMINATED) != 0, valid);
-        }
+        if (gp.write_film) film_add_wave(sc, rp.film, rp.lambda_tab, rp4.w & 0xffffu, rp4.z, l, (flags & FLAG_SECONDARY_TERMINATED) != 0, valid);
         __syncthreads();
         if (threadIdx.x == 0) rq.count[chunk] = sm_n;
     }

@@ -127,9 +127,12 @@ PT_D void film_add_rgb_wave(double* film, uint32_t pixel, const double rgb[3], b
         if (w) unsafeAtomicAdd(film + 3 * (size_t)px + c, c == 0u ? v0 : (c == 1u ? v1 : v2));
     }
 }
-PT_D void film_add_wave(const SceneDev& sc, double* film, uint32_t pixel, const Spec& l, const Lambdas& wl, bool sec_term, bool want) {
+PT_D void film_add_wave(const SceneDev& sc, double* film, const float4* lambda_tab, uint32_t row, uint32_t pixel, const Spec& l, bool sec_term, bool want) {
     double rgb[3] = {0.0, 0.0, 0.0};
-    if (want) spec_to_rgb(l, wl, sec_term, sc.cie_xyz, rgb);
+    if (want) {
+        const Lambdas wl = load_lambdas(lambda_tab, row, true);
+        spec_to_rgb(l, wl, sec_term, sc.cie_xyz, rgb);
+    }
     film_add_rgb_wave(film, pixel, rgb, want);
 }
 
@@ -139,6 +142,7 @@ struct RenderParams {
     uint32_t capacity;       // slots per state set
     uint32_t resx;           // image width (pixel index = x + y*resx)
     const float4* lambda_tab;  // per wavelength-table entry: 8 lambdas + 8 pdfs (see ptgpu.hip: wavelength tables)
+    SpecTab spec;            // the scene's spectra at every table entry's wavelengths
     double* film;            // resx*resy*3
 };
 
@@ -150,6 +154,25 @@ __global__ __launch_bounds__(kBlock) void k_build_lambda_table(const float* u, f
     tab[4 * (size_t)i + 1] = make_float4(w.l[4], w.l[5], w.l[6], w.l[7]);
     tab[4 * (size_t)i + 2] = make_float4(w.pdf[0], w.pdf[1], w.pdf[2], w.pdf[3]);
     tab[4 * (size_t)i + 3] = make_float4(w.pdf[4], w.pdf[5], w.pdf[6], w.pdf[7]);
+}
+
+// SpecTab builder: one thread per (spectrum, row).
+__global__ __launch_bounds__(kBlock) void k_build_spectrum_table(SceneDev sc, const float4* lambda_tab, uint32_t n_rows, uint32_t n_materials, uint32_t n_spectra,
+                                                              float4* out) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_spectra * n_rows) return;
+    const uint32_t spectrum = g / n_rows, row = g % n_rows;
+    const Lambdas wl = load_lambdas(lambda_tab, row, false);
+    SpectrumDev sd;
+    if (spectrum < 2 * n_materials) {
+        const MaterialDev m = sc.materials[spectrum / 2];
+        sd = (spectrum & 1u) ? m.s1 : m.s0;
+    } else {
+        sd = sc.emissions[spectrum - 2 * n_materials];
+    }
+    const Spec v = spectrum_eval(sd, wl, sc.d65);
+    out[2 * (size_t)g] = make_float4(v.v[0], v.v[1], v.v[2], v.v[3]);
+    out[2 * (size_t)g + 1] = make_float4(v.v[4], v.v[5], v.v[6], v.v[7]);
 }
 
 // ------------------------------------------------------------------ ray generation
@@ -257,7 +280,6 @@ __global__ __launch_bounds__(kBlock, PT_SHADE_WAVES) void k_shade_path(SceneDev 
         Spec beta = spec_splat(0.0f), L = spec_splat(0.0f), contrib = spec_splat(0.0f);
         uint4 rp4 = make_uint4(0, 0, 0, 0);
         V3 sh_from = mk3(0, 0, 0), sh_to = mk3(0, 0, 0);
-        Lambdas wl;
         if (valid) {
             const float4 o4 = in.o_pdf[i], d4 = in.d_flags[i];
             o = mk3(o4.x, o4.y, o4.z);
@@ -266,7 +288,6 @@ __global__ __launch_bounds__(kBlock, PT_SHADE_WAVES) void k_shade_path(SceneDev 
             flags = f2u(d4.w);
             rp4 = in.rng_px[i];
             L = load_spec(in.L0, in.L1, i);
-            wl = load_lambdas(rp.lambda_tab, rp4.w, true);
             const uint32_t prim = hit.prim[i];
             if (prim == kNoHit) {
                 do_film = true;  // eval_envmap == ZERO without an envmap (scene.rs:301-306)
@@ -290,18 +311,18 @@ __global__ __launch_bounds__(kBlock, PT_SHADE_WAVES) void k_shade_path(SceneDev 
                     flags &= ~FLAG_PASS_MASK;
                     const V3 wo = -d;
                     const V3 p = surf_p(sf);
-                    const Bsdf bsdf = make_bsdf<KINDS>(sc, material, wl);
+                    const Bsdf bsdf = make_bsdf<KINDS>(sc, rp.spec, material, rp4.w);
                     const bool spec_bounce = (flags & FLAG_SPECULAR_BOUNCE) != 0;
                     // emitted radiance of the surface that was hit (path_tracer.rs:82-108)
                     if (sf.tri.mesh < sc.n_emissive_meshes) {
                         const bool direct = (depth == 0) || spec_bounce;
                         if (rp.mode == MODE_PT || direct) {
-                            L = L + light_emitted(sc, sf.tri, sf.ng, p, o, wl) * beta;
+                            L = L + light_emitted(rp.spec, sf.tri, sf.ng, p, o, rp4.w) * beta;
                         } else if (rp.mode == MODE_MIS) {
                             const float pb = prev_pdf;
                             const float pl = light_pdf_li(sf.tri, sf.ng, prev_p, p);
                             const float w = (pb * pb) / (pb * pb + pl * pl);
-                            L = L + w * light_emitted(sc, sf.tri, sf.ng, p, o, wl) * beta;
+                            L = L + w * light_emitted(rp.spec, sf.tri, sf.ng, p, o, rp4.w) * beta;
                         }
                     }
                     Rng rng{(uint64_t)rp4.x | ((uint64_t)rp4.y << 32), rng_inc_for_pixel(rp4.z % rp.resx, rp4.z / rp.resx)};
@@ -315,7 +336,7 @@ __global__ __launch_bounds__(kBlock, PT_SHADE_WAVES) void k_shade_path(SceneDev 
                             Spec f = bsdf_eval(bsdf, sf.frame, sf.ng, wo, ls.wl, true) / (ls.pdf * pmf);
                             if (!spec_is_black(f)) {
                                 const V3 lp = (ls.blo + ls.bhi) / 2.0f;
-                                const Spec le = spectrum_eval(sc.emissions[lt.mesh], wl, sc.d65);
+                                const Spec le = spec_lookup(rp.spec, rp.spec.emission_base + lt.mesh, rp4.w);
                                 if (rp.mode == MODE_NEE) contrib = f * beta * le;
                                 else {
                                     const float pl = ls.pdf;
@@ -382,7 +403,7 @@ __global__ __launch_bounds__(kBlock, PT_SHADE_WAVES) void k_shade_path(SceneDev 
             sh.q1[s_slot] = make_float4(sh_to.x, sh_to.y, sh_to.z, 0.0f);
             store_spec(sh.q2, sh.q3, s_slot, contrib);
         }
-        film_add_wave(sc, rp.film, rp4.z, L, wl, (flags & FLAG_SECONDARY_TERMINATED) != 0, do_film && !spec_is_black(L));
+        film_add_wave(sc, rp.film, rp.lambda_tab, rp4.w, rp4.z, L, (flags & FLAG_SECONDARY_TERMINATED) != 0, do_film && !spec_is_black(L));
     }
     block_count_flush(&sm_count, &nxt->n_segments, n_shaded);
 }
@@ -453,7 +474,7 @@ __global__ __launch_bounds__(kBlock) void k_raygen_light(SceneDev sc, CameraDev 
             float pmf;
             LeSample le;
             if (choose_light(sc, u1d, lt, pmf) && light_sample_le(lt, u00, u01, u10, u11, le)) {
-                const Spec L = spectrum_eval(sc.emissions[lt.mesh], wl, sc.d65);
+                const Spec L = spec_lookup(rp.spec, rp.spec.emission_base + lt.mesh, (uint32_t)si);
                 const V3 lp = (le.blo + le.bhi) / 2.0f;
                 CameraWi cw;
                 if (camera_sample_wi(cam, lp, cw)) {
@@ -530,7 +551,7 @@ __global__ __launch_bounds__(kBlock, PT_SHADE_WAVES) void k_shade_light(SceneDev
                 shaded = true;
                 const V3 wo = -d;
                 const V3 p = surf_p(sf);
-                const Bsdf bsdf = make_bsdf<KINDS>(sc, material, wl);
+                const Bsdf bsdf = make_bsdf<KINDS>(sc, rp.spec, material, rp4.w);
                 CameraWi cw;
                 if (!bsdf_is_specular(bsdf) && camera_sample_wi(cam, p, cw)) {
                     Spec f = bsdf_eval(bsdf, sf.frame, sf.ng, wo, cw.wc, false) * spec_splat(cw.importance) * beta / cw.pdf;

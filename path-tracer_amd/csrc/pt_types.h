@@ -27,6 +27,15 @@ struct MaterialDev {
     float roughness;
     SpectrumDev s0, s1;
 };
+// Every spectrum of the scene evaluated at the eight wavelengths of every wavelength-table row (a path's hero sample
+// is one of a few hundred to a few thousand table rows): entry (spectrum, row) = two float4 at 2 * (spectrum * n_rows
+// + row). Spectrum ids: material m -> 2m (albedo | eta) and 2m + 1 (conductor k); emissive mesh e -> emission_base + e.
+// Built on the device by the same spectrum_eval the kernels would otherwise call per segment (same bits).
+struct SpecTab {
+    const float4* tab;
+    uint32_t n_rows;
+    uint32_t emission_base;
+};
 struct MeshInfo {
     int material;     // -1 = None (pass-through surface)
     int has_normals;

@@ -126,6 +126,9 @@ struct ptgpu_ctx {
     DevBuf<RoundCounters> d_counters;
     DevBuf<double> d_film;
     DevBuf<float> d_lambda_u;
+    DevBuf<float4> d_spec_tab;
+    SpecTab spec{nullptr, 0, 0};
+    uint32_t n_materials = 0, n_emissions = 0;  // entries of the device materials / emissions arrays
     DevBuf<float4> d_lambda_tab;  // 4 float4 per table entry: lambdas, pdfs
     std::vector<RoundCounters> h_counters;
     bool profiling = false;
@@ -410,6 +413,8 @@ int ptgpu_scene_create(ptgpu_ctx* c, const ptgpu_scene_desc* desc) {
     }
     HIP_TRY(c->d_materials.upload(mats, c->stream));
     HIP_TRY(c->d_emissions.upload(emissions, c->stream));
+    c->n_materials = (uint32_t)mats.size();
+    c->n_emissions = (uint32_t)emissions.size();
     HIP_TRY(c->d_emissive.upload(emissive_leaf, c->stream));
     SceneDev& s = c->scene;
     s.nodes = c->d_nodes.p;
@@ -582,6 +587,15 @@ int upload_lambda_table(ptgpu_ctx* c, const std::vector<float>& u) {
     const uint32_t n = (uint32_t)u.size();
     hipLaunchKernelGGL(k_build_lambda_table, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, c->d_lambda_u.p, c->d_lambda_tab.p, n);
     HIP_TRY(hipGetLastError());
+    // every spectrum of the scene at every row's wavelengths (SpecTab, pt_types.h)
+    const uint32_t n_spectra = 2 * c->n_materials + c->n_emissions;
+    const uint64_t cells = (uint64_t)n_spectra * n;
+    if (cells > 0x7fffffffull) return fail(PTGPU_E_LIMIT, "render: materials x wavelength samples too large for the spectrum table");
+    HIP_TRY(c->d_spec_tab.reserve(2 * cells));
+    hipLaunchKernelGGL(k_build_spectrum_table, dim3((uint32_t)((cells + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream, c->scene, c->d_lambda_tab.p, n, c->n_materials,
+                       n_spectra, c->d_spec_tab.p);
+    HIP_TRY(hipGetLastError());
+    c->spec = SpecTab{c->d_spec_tab.p, n, 2 * c->n_materials};
     return PTGPU_OK;
 }
 
@@ -684,6 +698,7 @@ int render_path_like(ptgpu_ctx* c, const ptgpu_integrator_desc* integ, uint32_t 
     rp.capacity = c->capacity;
     rp.resx = c->camera.resx;
     rp.lambda_tab = c->d_lambda_tab.p;
+    rp.spec = c->spec;
     rp.film = c->d_film.p;
     const uint64_t passes_per_batch = c->capacity / npix;
     for (uint64_t done = 0; done < my_samples; done += passes_per_batch) {
