@@ -298,11 +298,25 @@ PT_D bool guider_sample(const SdTreeDev& t, const Bsdf& bsdf, const Frame& fr, V
 // DTree::record with the box filter (dtree.rs:200-207,235-289): weight += 1; splat `radiance` over every collector
 // leaf cell the footprint (a box of the size of the cell containing p, centred on p, clipped to the unit square)
 // overlaps, in proportion to the overlap. f32 atomics straight into HBM.
-PT_D void dtree_record_box(const SdTreeDev& t, uint32_t leaf_id, uint4 leaf, V2 p, float radiance) {
-    unsafeAtomicAdd(t.c_weight + leaf_id, 1.0f);
-    // DTree::leaf (dtree.rs:81-94): the cell that holds p
-    Cell cell{0, 0, 0};
-    {
+//
+// Called by the WHOLE wave (`active` marks lanes that carry a record). Float atomics cost one memory-side request per
+// 64-byte line per wave instruction, so the four child sums of a node (16 contiguous bytes) are not added by the lane
+// that computed them, one instruction per child, but by the four lanes of its quad in one instruction: the quad takes
+// its members' nodes in turn, lane j adding child j's share. A footprint that covers sibling cells then costs one
+// request instead of up to four.
+PT_D void dtree_record_box(const SdTreeDev& t, uint32_t leaf_id, uint4 leaf, V2 p, float radiance, bool active) {
+    struct Item {
+        uint32_t node;
+        Cell cell;
+    };
+    Item stack[3 * kMaxQuadLevel + 4];
+    int sp = 0;
+    Box2 fp{{0.0f, 0.0f}, {0.0f, 0.0f}};
+    float fp_area = 0.0f;
+    if (active) {
+        unsafeAtomicAdd(t.c_weight + leaf_id, 1.0f);
+        // DTree::leaf (dtree.rs:81-94): the cell that holds p
+        Cell cell{0, 0, 0};
         uint32_t ni = 0;
         for (;;) {
             Cell child;
@@ -312,46 +326,70 @@ PT_D void dtree_record_box(const SdTreeDev& t, uint32_t leaf_id, uint4 leaf, V2 
             if (link == 0 || child.level >= kMaxQuadLevel) break;
             ni = link;
         }
+        const Box2 lb = cell_box(cell);
+        fp = box2_around(p, box2_extent(lb));
+        fp = Box2{clamp2(V2{0.0f, 0.0f}, fp.lo, fp.hi), clamp2(V2{1.0f, 1.0f}, fp.lo, fp.hi)};  // Bounds2::clamp (bounds.rs:46-50)
+        fp_area = box2_area(fp);
+        stack[sp++] = Item{0, Cell{0, 0, 0}};
     }
-    const Box2 lb = cell_box(cell);
-    Box2 fp = box2_around(p, box2_extent(lb));
-    fp = Box2{clamp2(V2{0.0f, 0.0f}, fp.lo, fp.hi), clamp2(V2{1.0f, 1.0f}, fp.lo, fp.hi)};  // Bounds2::clamp (bounds.rs:46-50)
-    const float fp_area = box2_area(fp);
+    const uint32_t lane = __lane_id(), quad_base = lane & ~3u, me = lane & 3u;
     // depth-first over (node, cell) pairs; children visited in index order like the recursion
-    struct Item {
-        uint32_t node;
-        Cell cell;
-    };
-    Item stack[3 * kMaxQuadLevel + 4];
-    int sp = 0;
-    stack[sp++] = Item{0, Cell{0, 0, 0}};
-    while (sp > 0) {
-        const Item it = stack[--sp];
-        const uint2 links = t.c_child[leaf.y + it.node];
-        float* rad = reinterpret_cast<float*>(t.c_rad + leaf.y + it.node);
-        for (int c = 3; c >= 0; c--) {  // pushed in reverse so that child 0 is expanded first
-            const Cell child{2 * it.cell.ix + (uint32_t)(c & 1), 2 * it.cell.iy + (uint32_t)(c >> 1), it.cell.level + 1};
-            const float w = box2_overlap(fp, cell_box(child)) / fp_area;
-            if (w == 0.0f || !(w == w)) continue;
-            const uint32_t link = child_link(links, c);
-            if (link == 0 || child.level >= kMaxQuadLevel) unsafeAtomicAdd(rad + c, radiance * w);
-            else if (sp < (int)(sizeof(stack) / sizeof(stack[0]))) stack[sp++] = Item{link, child};
+    while (__ballot(sp > 0) != 0ull) {
+        float share[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        uint32_t node_index = 0;  // arena index of the node whose children get `share`
+        if (sp > 0) {
+            const Item it = stack[--sp];
+            node_index = leaf.y + it.node;
+            const uint2 links = t.c_child[node_index];
+            // The four children share three x and three y coordinates, so the overlap with the footprint is two 1-D
+            // extents per axis; the values are those of Bounds2::overlap on cell_box(child) (same operands, same order).
+            const float cs = u2f((127u - (it.cell.level + 1)) << 23);  // child cell size
+            const float x0 = (float)(2 * it.cell.ix) * cs, xm = (float)(2 * it.cell.ix + 1) * cs, x1 = (float)(2 * it.cell.ix + 2) * cs;
+            const float y0 = (float)(2 * it.cell.iy) * cs, ym = (float)(2 * it.cell.iy + 1) * cs, y1 = (float)(2 * it.cell.iy + 2) * cs;
+            const float ex[2] = {fminf(fp.hi.x, xm) - fmaxf(fp.lo.x, x0), fminf(fp.hi.x, x1) - fmaxf(fp.lo.x, xm)};
+            const float ey[2] = {fminf(fp.hi.y, ym) - fmaxf(fp.lo.y, y0), fminf(fp.hi.y, y1) - fmaxf(fp.lo.y, ym)};
+#pragma unroll
+            for (int c = 3; c >= 0; c--) {  // pushed in reverse so that child 0 is expanded first
+                const float ox = ex[c & 1], oy = ey[c >> 1];
+                if (ox <= 0.0f || oy <= 0.0f) continue;  // overlap 0 => weight 0 (or 0/0): skipped by the reference too
+                const float w = (ox * oy) / fp_area;
+                if (w == 0.0f || !(w == w)) continue;
+                const uint32_t link = child_link(links, c);
+                const uint32_t child_level = it.cell.level + 1;
+                if (link == 0 || child_level >= kMaxQuadLevel) share[c] = radiance * w;
+                else if (sp < (int)(sizeof(stack) / sizeof(stack[0])))
+                    stack[sp++] = Item{link, Cell{2 * it.cell.ix + (uint32_t)(c & 1), 2 * it.cell.iy + (uint32_t)(c >> 1), child_level}};
+            }
+        }
+#pragma unroll
+        for (uint32_t r = 0; r < 4; r++) {
+            const int src = (int)(quad_base + r);
+            const uint32_t node_r = (uint32_t)__shfl((int)node_index, src);
+            const float s0 = __shfl(share[0], src), s1 = __shfl(share[1], src), s2 = __shfl(share[2], src), s3 = __shfl(share[3], src);
+            const float mine = me == 0u ? s0 : (me == 1u ? s1 : (me == 2u ? s2 : s3));
+            if (mine != 0.0f) unsafeAtomicAdd(reinterpret_cast<float*>(t.c_rad + node_r) + me, mine);
         }
     }
 }
 
 // STree::record with the stochastic spatial filter (stree.rs:102-116,186-201); the caller has checked that
 // `radiance` is finite and non-zero and has drawn the three jitter numbers.
-PT_D void stree_record_jittered(const SdTreeDev& t, V3 p, V3 wi, float radiance, float u0, float u1, float u2) {
-    const V2 p2 = dir_to_square(wi);
-    V3 lo, hi;
-    (void)stree_leaf<true>(t, p, lo, hi);
-    const V3 ext = hi - lo;
-    const V3 jlo = p - ext / 2.0f;  // Bounds3::around(p, extent)
-    const V3 jhi = p + ext / 2.0f;
-    const V3 q = clamp3(jlo + mk3(u0, u1, u2) * (jhi - jlo), t.blo, t.bhi);
-    const uint32_t leaf_id = stree_leaf<false>(t, q, lo, hi);
-    dtree_record_box(t, leaf_id, t.leaf_info[leaf_id], p2, radiance);
+PT_D void stree_record_jittered(const SdTreeDev& t, V3 p, V3 wi, float radiance, float u0, float u1, float u2, bool active) {
+    V2 p2 = V2{0.0f, 0.0f};
+    uint32_t leaf_id = 0;
+    uint4 leaf = make_uint4(0, 0, 0, 0);
+    if (active) {
+        p2 = dir_to_square(wi);
+        V3 lo, hi;
+        (void)stree_leaf<true>(t, p, lo, hi);
+        const V3 ext = hi - lo;
+        const V3 jlo = p - ext / 2.0f;  // Bounds3::around(p, extent)
+        const V3 jhi = p + ext / 2.0f;
+        const V3 q = clamp3(jlo + mk3(u0, u1, u2) * (jhi - jlo), t.blo, t.bhi);
+        leaf_id = stree_leaf<false>(t, q, lo, hi);
+        leaf = t.leaf_info[leaf_id];
+    }
+    dtree_record_box(t, leaf_id, leaf, p2, radiance, active);  // wave-cooperative
 }
 
 struct GuidedParams {
@@ -690,10 +728,17 @@ __global__ __launch_bounds__(kBlock) void k_guide_splat(SdTreeDev tree, GuidedPa
     for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
         const uint32_t n = rq.count[chunk];
         const size_t base = (size_t)chunk * kBlock * gp.n_rows;
-        for (uint32_t j = threadIdx.x; j < n; j += kBlock) {
-            const float4 a = rq.q0[base + j], b = rq.q1[base + j];
-            const float2 c = rq.q2[base + j];
-            stree_record_jittered(tree, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), a.w, b.w, c.x, c.y);
+        for (uint32_t j0 = 0; j0 < n; j0 += kBlock) {  // block-uniform trip count: the record is wave-cooperative
+            const uint32_t j = j0 + threadIdx.x;
+            const bool active = j < n;
+            float4 a = make_float4(0, 0, 0, 0), b = make_float4(0, 0, 0, 0);
+            float2 c = make_float2(0, 0);
+            if (active) {
+                a = rq.q0[base + j];
+                b = rq.q1[base + j];
+                c = rq.q2[base + j];
+            }
+            stree_record_jittered(tree, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), a.w, b.w, c.x, c.y, active);
         }
     }
 }
