@@ -101,6 +101,7 @@ struct StateSet {
 struct ptgpu_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;  // guided: the record pass of batch b runs here while `stream` walks batch b + 1
     int n_cus = 256;
     // scene
     bool have_scene = false, have_camera = false;
@@ -193,7 +194,8 @@ struct StageTimer {
     int stage;
     size_t pair = 0;
     bool on = false;
-    StageTimer(ptgpu_ctx* c_, int stage_) : c(c_), stage(stage_) {
+    hipStream_t s;
+    StageTimer(ptgpu_ctx* c_, int stage_, hipStream_t stream_ = nullptr) : c(c_), stage(stage_), s(stream_ ? stream_ : c_->stream) {
         if (!c->profiling) return;
         pair = c->ev_stage.size();
         while (c->ev_pool.size() < 2 * (pair + 1)) {
@@ -203,12 +205,12 @@ struct StageTimer {
         }
         c->ev_stage.push_back(stage);
         on = true;
-        (void)hipEventRecord(c->ev_pool[2 * pair], c->stream);
+        (void)hipEventRecord(c->ev_pool[2 * pair], s);
     }
     ~StageTimer() {
         c->launches++;
         c->stage_launches[stage]++;
-        if (on) (void)hipEventRecord(c->ev_pool[2 * pair + 1], c->stream);
+        if (on) (void)hipEventRecord(c->ev_pool[2 * pair + 1], s);
     }
 };
 // Turns the recorded event pairs into per-stage totals; call after the stream has been synchronised.
@@ -265,6 +267,7 @@ int ptgpu_init(ptgpu_ctx** out, int device_id) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) c->n_cus = prop.multiProcessorCount;
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking);
     if (e == hipSuccess) e = c->d_census.alloc(4);
     if (e == hipSuccess) e = hipMemset(c->d_census.p, 0, 4 * sizeof(unsigned long long));
     if (e == hipSuccess) e = c->d_d65.upload(std::vector<float>(kD65, kD65 + CIE_N), c->stream);
@@ -281,10 +284,12 @@ void ptgpu_destroy(ptgpu_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    if (c->stream2) (void)hipStreamSynchronize(c->stream2);
     guided_free(c->guided);
     guided_persist_free(c->guided_persist);
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->stream2) (void)hipStreamDestroy(c->stream2);
     delete c;
 }
 
