@@ -266,8 +266,11 @@ int ptgpu_init(ptgpu_ctx** out, int device_id) {
     c->device = device_id;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) c->n_cus = prop.multiProcessorCount;
-    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking);
+    // the main stream carries the critical path (the walk); the guided record pass fills in behind it at low priority
+    int prio_least = 0, prio_greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+    hipError_t e = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_greatest);
+    if (e == hipSuccess) e = hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_least);
     if (e == hipSuccess) e = c->d_census.alloc(4);
     if (e == hipSuccess) e = hipMemset(c->d_census.p, 0, 4 * sizeof(unsigned long long));
     if (e == hipSuccess) e = c->d_d65.upload(std::vector<float>(kD65, kD65 + CIE_N), c->stream);
