@@ -57,10 +57,18 @@ def main() -> int:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    # PT_BENCH_FORCE_DIST=1: rehearse the RCCL code path (process group, in-place all-reduce of the library's statistics
+    # buffer, film reduce) with a one-rank group on a one-GPU box
+    force_dist = world == 1 and os.environ.get("PT_BENCH_FORCE_DIST") == "1"
+    if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if force_dist:
+            os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    use_dist = world > 1 or force_dist
     if world != args.gpus and rank == 0:
         print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
     dev = torch.device("cuda", local_rank)
@@ -75,17 +83,17 @@ def main() -> int:
     ctx.load(sc)
     integ = pt.IntegratorDesc.from_buffer_copy(sc.integrator)
     guided = integ.kind == pt.INTEGRATOR_GUIDED
-    film_dev = torch.zeros((resy, resx, 3), dtype=torch.float64, device=dev) if world > 1 else None
+    film_dev = torch.zeros((resy, resx, 3), dtype=torch.float64, device=dev) if use_dist else None
 
     wrap = mg.device_stats_tensor(torch, dev)
 
     def step():
         """One render of the whole workload; returns (film sums on rank 0, film_scale, stats of this rank)."""
         return mg.render_sharded(ctx, integ, spp, rank, world, guided, dist=dist, wrap_stats=wrap, film_buf=film_dev,
-                                 sync=lambda: torch.cuda.synchronize(dev))
+                                 sync=lambda: torch.cuda.synchronize(dev), collectives=use_dist)
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -107,7 +115,7 @@ def main() -> int:
     fence()
     elapsed = time.perf_counter() - t0
     ctx.set_profiling(False)
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -206,7 +214,7 @@ def main() -> int:
         "roofline": roofline, "cpu_baseline": cpu,
     }
     print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     return 0

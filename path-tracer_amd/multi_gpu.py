@@ -35,7 +35,7 @@ def device_stats_tensor(torch, dev):
     return lambda ptr, count: torch.as_tensor(DeviceArray(ptr, count), device=dev)
 
 
-def render_sharded(ctx, integ, spp, rank, world, guided, dist=None, wrap_stats=None, film_buf=None, sync=lambda: None):
+def render_sharded(ctx, integ, spp, rank, world, guided, dist=None, wrap_stats=None, film_buf=None, sync=lambda: None, collectives=None):
     """One render of the whole job on this rank's shard. Returns (film sums [complete on rank 0], film_scale, stats).
 
     ctx       : object with render(integ, spp, rank, world) and guided_{begin,wave,stats,end} (path_tracer_amd.Context)
@@ -43,12 +43,15 @@ def render_sharded(ctx, integ, spp, rank, world, guided, dist=None, wrap_stats=N
     wrap_stats: (ptr_or_buffer, count) -> tensor aliasing the statistics buffer
     film_buf  : preallocated float64 tensor (H, W, 3) on the collective's device
     sync      : waits for the collective's stream (torch.cuda.synchronize on GPU)
+    collectives: run the collectives even when world == 1 (rehearsal of the RCCL path on a one-GPU box); default world > 1
     """
+    if collectives is None:
+        collectives = world > 1
     if guided:
         n_waves = ctx.guided_begin(integ, spp, rank, world)
         for w in range(n_waves):
             ctx.guided_wave(w)
-            if world > 1 and w + 1 < n_waves:
+            if collectives and w + 1 < n_waves:
                 ptr, count = ctx.guided_stats()
                 t = wrap_stats(ptr, count)
                 dist.all_reduce(t, op=dist.ReduceOp.SUM)
@@ -56,7 +59,7 @@ def render_sharded(ctx, integ, spp, rank, world, guided, dist=None, wrap_stats=N
         film, scale, st = ctx.guided_end()
     else:
         film, scale, st = ctx.render(integ, spp, rank, world)
-    if world > 1:
+    if collectives:
         import torch
         film_buf.copy_(torch.from_numpy(np.ascontiguousarray(film)))
         dist.reduce(film_buf, dst=0, op=dist.ReduceOp.SUM)

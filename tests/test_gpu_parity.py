@@ -2,6 +2,8 @@
 same seeded inputs. Integer / index / hit-record work is compared bit for bit; images statistically (relMSE),
 because device libm (sin, cos, log1p, cosh, atan2) differs from glibc in the last ulp and a single flipped
 discrete decision re-routes a path."""
+from pathlib import Path
+
 import numpy as np
 import pytest
 
@@ -266,3 +268,21 @@ def test_guided_shards_cover_every_sample_once(gpu_ctx):
         _, _, st = gpu_ctx.render(sc.integrator, 7, k, 3)
         total += st["samples"]
     assert total == 48 * 40 * 7
+
+
+# ------------------------------------------------------------------ multi-GPU driver rehearsal on one GPU
+@pytest.mark.parametrize("workload", ["guided", "path"])
+def test_bench_rccl_path_rehearsal(workload):
+    """bench.py with a ONE-rank RCCL group (PT_BENCH_FORCE_DIST=1): process-group set-up, the in-place all-reduce on
+    the library's statistics buffer (zero-copy tensor over the raw device pointer), the film reduce and the timing
+    collectives all run for real; only the number of ranks is 1 (the box has one GPU)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, PT_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
+    r = subprocess.run([sys.executable, str(Path(__file__).resolve().parent.parent / "bench.py"), "--workload", workload, "--steps", "1", "--warmup", "0",
+                        "--spp", "16", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["value"] > 0 and line["roofline"]["achieved"] > 0
