@@ -342,6 +342,7 @@ PT_HD bool ray_triangle(V3 ro, const RayShear& rs, V3 p0, V3 p1, V3 p2, float ma
 // force the whole wave through one box phase per leaf; leaves and triangles are still tested in the reference's order.
 struct Hit {
     uint32_t prim;  // leaf-order triangle index, kNoHit = miss
+    uint32_t tag;   // tri_v[3 * prim + 2].w of the hit triangle
     TriHit th;
 };
 // ANY_HIT (occlusion queries only): Scene::occluded keeps no more than "was anything hit" (scene.rs:229-235). Once
@@ -354,6 +355,7 @@ PT_D Hit bvh_intersect(const SceneDev& sc, V3 o, V3 d, float ray_end_t, uint32_t
     uint32_t* stack = sm_bvh_stack + threadIdx.x;
     Hit best;
     best.prim = kNoHit;
+    best.tag = 0;
     best.th.t = ray_end_t;
     best.th.b0 = best.th.b1 = best.th.b2 = 0.0f;
     const V3 inv = splat(1.0f) / d;
@@ -424,6 +426,8 @@ PT_D Hit bvh_intersect(const SceneDev& sc, V3 o, V3 d, float ray_end_t, uint32_t
         }
     }
     if (!(best.th.t != ray_end_t)) best.prim = kNoHit;  // bvh.rs:137
+    // fetched once per ray here rather than carried through the walk (a register the loop does not have to spare)
+    if (!ANY_HIT && best.prim != kNoHit) best.tag = f2u(sc.tri_v[3 * best.prim + 2].w);
     return best;
 }
 // Scene::occluded (scene.rs:229-235): unnormalised segment, t_max 0.9999; only the boolean leaves this function.

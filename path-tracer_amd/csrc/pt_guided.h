@@ -43,7 +43,7 @@ void guided_persist_free(GuidedPersist* p);
 // ptgpu_guided_stats hands to the multi-GPU driver for its all-reduce.
 struct SdTreeDev {
     const uint4* snodes;
-    const uint32_t* top;  // jump table over the first kStreeTopLevels decisions (sdtree_host.h)
+    const uint2* top;  // {entry, sampler word of the leaf}: jump table over the first kStreeTopLevels decisions (sdtree_host.h)
     const uint4* leaf_info;
     const float4* s_rad;
     const uint2* s_child;
@@ -75,8 +75,9 @@ PT_D V2 dir_to_square(V3 d) {  // path_guiding/mod.rs:412-421
 // STree::leaf (stree.rs:202-229): halve along the node's axis until a leaf; also returns the leaf's box.
 // The first kStreeTopLevels halvings are done without touching the tree (axis = depth % 3, split at the midpoint:
 // the decisions are the reference's, bit for bit) and index a jump table; only deeper levels chase node links.
+// `sampler_word` (optional) receives the leaf's sampling-arena offset | mean_is_zero << 31.
 template <bool WANT_BOX>
-PT_D uint32_t stree_leaf(const SdTreeDev& t, V3 p, V3& lo, V3& hi) {
+PT_D uint32_t stree_leaf(const SdTreeDev& t, V3 p, V3& lo, V3& hi, uint32_t* sampler_word = nullptr) {
     lo = t.blo;
     hi = t.bhi;
     uint32_t code = 0;
@@ -89,8 +90,10 @@ PT_D uint32_t stree_leaf(const SdTreeDev& t, V3 p, V3& lo, V3& hi) {
         if (right) set(lo, ax, mid);
         else set(hi, ax, mid);
     }
-    const uint32_t entry = t.top[code];
+    const uint2 entry2 = t.top[code];
+    const uint32_t entry = entry2.x;
     if (entry & 0x80000000u) {
+        if (sampler_word) *sampler_word = entry2.y;
         if (WANT_BOX) {  // the leaf sits above the table's depth: redo its (fewer) halvings for the box
             const uint32_t depth = entry & 31u;
             lo = t.blo;
@@ -107,7 +110,10 @@ PT_D uint32_t stree_leaf(const SdTreeDev& t, V3 p, V3& lo, V3& hi) {
     uint32_t ni = entry >> 5;
     for (int guard = 0; guard < 128; guard++) {
         const uint4 n = t.snodes[ni];
-        if (n.x == 0) return n.w;
+        if (n.x == 0) {
+            if (sampler_word) *sampler_word = n.y;
+            return n.w;
+        }
         const int ax = (int)n.z;
         const float mid = (get(lo, ax) + get(hi, ax)) / 2.0f;
         if (get(p, ax) < mid) {
@@ -118,6 +124,7 @@ PT_D uint32_t stree_leaf(const SdTreeDev& t, V3 p, V3& lo, V3& hi) {
             ni = n.y;
         }
     }
+    if (sampler_word) *sampler_word = t.snodes[ni].y;
     return t.snodes[ni].w;
 }
 
@@ -264,7 +271,9 @@ PT_D bool guider_sample(const SdTreeDev& t, const Bsdf& bsdf, const Frame& fr, V
         return bsdf_sample(bsdf, fr, ng, wo, u1d, ua, ub, true, s);
     }
     V3 lo, hi;
-    const uint4 leaf = t.leaf_info[stree_leaf<false>(t, p, lo, hi)];
+    uint32_t sampler_word = 0;
+    (void)stree_leaf<false>(t, p, lo, hi, &sampler_word);
+    const uint4 leaf = make_uint4(sampler_word & 0x7fffffffu, 0u, sampler_word >> 31, 0u);  // leaf_info's x and z
     PT_TICK(3);
     // Both branches need the tree's pdf at the chosen direction: one quadtree descent per wave serves the lanes
     // that sample from the tree and the lanes that only evaluate it (dtree_walk). Values are unchanged.
@@ -492,7 +501,8 @@ __global__ __launch_bounds__(kBlock, KINDS != 7 ? PT_GUIDED_DIFFUSE_WAVES : PT_S
             prev_p = mk3(pp.x, pp.y, pp.z);
             pid = f2u(pp.w);
             nverts = rp4.w >> 16;
-            const uint32_t prim = hit.prim[i];
+            const uint2 prim_tag = hit.prim[i];
+            const uint32_t prim = prim_tag.x;
             PT_TICK(0);
             if (prim == kNoHit) {
                 // miss vertex (mod.rs:140-150): far point along the ray, nothing emitted without an envmap
@@ -506,7 +516,7 @@ __global__ __launch_bounds__(kBlock, KINDS != 7 ? PT_GUIDED_DIFFUSE_WAVES : PT_S
                 beta = load_spec(in.beta0, in.beta1, i);
                 const uint32_t row = rp4.w & 0xffffu;  // wavelength-table row of this path
                 const Surface sf = make_surface(sc, prim, tb.y, tb.z, tb.w);
-                const int material = tri_material(sf.tri);
+                const int material = (int)(prim_tag.y & 0x7fffffffu) - 1;
                 uint32_t depth = flags & FLAG_DEPTH_MASK;
                 if (material < 0) {
                     // pass-through: no bounce counted and, unlike `path`, specular_bounce is left alone (mod.rs:153-156)

@@ -213,7 +213,7 @@ __global__ __launch_bounds__(kBlock) void k_extend(SceneDev sc, PathCols st, Hit
         const float4 o = st.o_pdf[i], d = st.d_flags[i];
         const Hit h = bvh_intersect<CENSUS>(sc, mk3(o.x, o.y, o.z), mk3(d.x, d.y, d.z), f_inf(), &cn, &ct);
         hit.tb[i] = make_float4(h.th.t, h.th.b0, h.th.b1, h.th.b2);
-        hit.prim[i] = h.prim;
+        hit.prim[i] = make_uint2(h.prim, h.tag);
     }
     if (CENSUS) census_add(census, 0, cn, ct);
 }
@@ -288,7 +288,8 @@ __global__ __launch_bounds__(kBlock, PT_SHADE_WAVES) void k_shade_path(SceneDev 
             flags = f2u(d4.w);
             rp4 = in.rng_px[i];
             L = load_spec(in.L0, in.L1, i);
-            const uint32_t prim = hit.prim[i];
+            const uint2 prim_tag = hit.prim[i];
+            const uint32_t prim = prim_tag.x;
             if (prim == kNoHit) {
                 do_film = true;  // eval_envmap == ZERO without an envmap (scene.rs:301-306)
             } else {
@@ -298,7 +299,7 @@ __global__ __launch_bounds__(kBlock, PT_SHADE_WAVES) void k_shade_path(SceneDev 
                 pid = f2u(pp.w);
                 beta = load_spec(in.beta0, in.beta1, i);
                 const Surface sf = make_surface(sc, prim, tb.y, tb.z, tb.w);
-                const int material = tri_material(sf.tri);
+                const int material = (int)(prim_tag.y & 0x7fffffffu) - 1;
                 uint32_t depth = flags & FLAG_DEPTH_MASK;
                 if (material < 0) {
                     // no BSDF: continue straight on, do not count a bounce (path_tracer.rs:76-80)
@@ -532,7 +533,7 @@ __global__ __launch_bounds__(kBlock, PT_SHADE_WAVES) void k_shade_light(SceneDev
         Spec beta = spec_splat(0.0f);
         uint4 rp4 = make_uint4(0, 0, 0, 0);
         double rgb[3] = {0.0, 0.0, 0.0};
-        if (i < n && hit.prim[i] != kNoHit) {
+        if (i < n && hit.prim[i].x != kNoHit) {
             const float4 o4 = in.o_pdf[i], d4 = in.d_flags[i];
             o = mk3(o4.x, o4.y, o4.z);
             d = mk3(d4.x, d4.y, d4.z);
@@ -541,8 +542,9 @@ __global__ __launch_bounds__(kBlock, PT_SHADE_WAVES) void k_shade_light(SceneDev
             beta = load_spec(in.beta0, in.beta1, i);
             const float4 tb = hit.tb[i];
             const Lambdas wl = load_lambdas(rp.lambda_tab, rp4.w, true);
-            const Surface sf = make_surface(sc, hit.prim[i], tb.y, tb.z, tb.w);
-            const int material = tri_material(sf.tri);
+            const uint2 prim_tag = hit.prim[i];
+            const Surface sf = make_surface(sc, prim_tag.x, tb.y, tb.z, tb.w);
+            const int material = (int)(prim_tag.y & 0x7fffffffu) - 1;
             uint32_t depth = (flags & FLAG_DEPTH_MASK) + 1;  // iterations consumed including this one
             if (material < 0) {
                 o = offset_ray_origin(sf.blo, sf.bhi, sf.ng, d);

@@ -42,9 +42,10 @@ constexpr size_t kPathBytes = 8 * 16;  // bytes of state per slot
 
 struct HitCols {
     float4* tb;      // t, b0, b1, b2
-    uint32_t* prim;  // leaf-order triangle index or kNoHit
+    uint2* prim;     // {leaf-order triangle index or kNoHit, the triangle's tag (material + 1 | has_normals << 31)}:
+                     // with the tag in the hit record, shade's material and spectrum loads do not wait for the triangle fetch
 };
-constexpr size_t kHitBytes = 16 + 4;
+constexpr size_t kHitBytes = 16 + 8;
 
 // Shadow / connection ray queue entry (64 B):
 //   q0 = {from.xyz, bits(target)}     target = slot | kTerminalBit (path), pixel (lightpath), vertex row (guided)

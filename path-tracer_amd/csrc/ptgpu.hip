@@ -122,7 +122,7 @@ struct ptgpu_ctx {
     uint32_t capacity = 0;
     StateSet set_a, set_b;
     DevBuf<float4> d_hit_tb;
-    DevBuf<uint32_t> d_hit_prim;
+    DevBuf<uint2> d_hit_prim;
     DevBuf<float4> d_shadow;  // q0 | q1 | q2,q3 contiguous (4 * capacity)
     DevBuf<RoundCounters> d_counters;
     DevBuf<double> d_film;

@@ -184,9 +184,12 @@ void HostSdTree::flatten(SdTreeFlat& out) const {
             continue;
         }
         const uint32_t leaf = (uint32_t)out.leaf_info.size();
-        out.snodes[i] = make_uint4(0, 0, n.axis, leaf);
         // DTree::mean() == 0 (dtree.rs:71-77) decides between uniform and tree sampling
         const float mean = n.sampler.weight == 0.0f ? 0.0f : n.sampler.nodes[0].sum() / (kFourPi * n.sampler.weight);
+        // sampler word = sampling-arena offset | mean_is_zero << 31: what Guider::sample needs of the leaf, handed out
+        // by the descent itself (leaf node / jump table) so that no leaf_info load follows it
+        const uint32_t sampler_word = (uint32_t)s_total | (mean == 0.0f ? 0x80000000u : 0u);
+        out.snodes[i] = make_uint4(0, sampler_word, n.axis, leaf);
         out.leaf_info.push_back(make_uint4((uint32_t)s_total, (uint32_t)c_total, mean == 0.0f ? 1u : 0u, 0u));
         out.leaf_snode.push_back((uint32_t)i);
         s_total += n.sampler.nodes.size();
@@ -211,7 +214,8 @@ void HostSdTree::flatten(SdTreeFlat& out) const {
             const uint32_t entry = n.left == 0 ? (0x80000000u | (out.snodes[it.node].w << 5) | it.depth) : ((it.node << 5) | it.depth);
             const uint32_t span = 1u << (kStreeTopLevels - it.depth);
             const uint32_t first = it.prefix << (kStreeTopLevels - it.depth);
-            for (uint32_t k = 0; k < span; k++) out.top[first + k] = entry;
+            const uint2 e2 = make_uint2(entry, n.left == 0 ? out.snodes[it.node].y : 0u);
+            for (uint32_t k = 0; k < span; k++) out.top[first + k] = e2;
         }
     }
     out.s_rad.resize(s_total);

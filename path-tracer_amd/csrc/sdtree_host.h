@@ -67,8 +67,8 @@ struct HostSNode {  // STreeNode (stree.rs:12-19)
 
 // Flat device image of the tree (see pt_guided.h for how the kernels read it).
 struct SdTreeFlat {
-    PinnedVec<uint4> snodes;            // {left, right, axis, leaf_id}
-    PinnedVec<uint32_t> top;            // kStreeTopLevels-bit descent code -> packed node / leaf (pt_guided.h: stree_leaf)
+    PinnedVec<uint4> snodes;            // {left, right, axis, leaf_id}; a leaf keeps its sampler word (below) in .y
+    PinnedVec<uint2> top;               // kStreeTopLevels-bit descent code -> packed node / leaf (pt_guided.h: stree_leaf)
     PinnedVec<uint4> leaf_info;         // per leaf: {sampler node offset, collector node offset, mean_is_zero, 0}
     PinnedVec<float4> s_rad;            // sampler arena
     PinnedVec<uint2> s_child;
