@@ -668,7 +668,7 @@ int run_batch_path_like(ptgpu_ctx* c, bool light, const RenderParams& rp, uint32
         HIP_TRY(hipGetLastError());
         std::swap(A, B);
         round++;
-        if (round >= sure_rounds || (round & 3) == 0) {
+        if (round >= sure_rounds || (round & 15) == 0) {  // the host looks at the queue length rarely: every look drains the stream
             RoundCounters rc;
             HIP_TRY(hipMemcpyAsync(&rc, cnt + round, sizeof(rc), hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(hipStreamSynchronize(c->stream));
