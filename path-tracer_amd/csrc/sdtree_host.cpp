@@ -3,6 +3,8 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <thread>
 #include <utility>
@@ -76,7 +78,8 @@ bool add_node(HostDTree& t, const HostDNode& n, uint16_t* index) {
 // DTree::subdivide_and_clear (dtree.rs:291-324): drop subtrees carrying < threshold of the total, split leaves
 // carrying more, then zero every sum and the weight.
 bool refine_directional(HostDTree& t, float threshold) {
-    std::vector<std::pair<uint16_t, int>> todo;
+    static thread_local std::vector<std::pair<uint16_t, int>> todo;  // re-used: one heap allocation per thread, not per leaf
+    todo.clear();
     todo.emplace_back((uint16_t)0, 1);
     const float total = t.nodes[0].sum();
     while (!todo.empty()) {
@@ -131,39 +134,59 @@ void HostSdTree::init(V3 lo, V3 hi) {
 bool HostSdTree::new_iteration(float directional_threshold, float spatial_threshold, uint32_t iteration, std::string* err) {
     // subdivide_nodes (stree.rs:55-101): threshold = base * sqrt(2^iteration); freshly appended children are
     // visited by the same sweep and may split again.
+    const auto t_begin = std::chrono::steady_clock::now();
     float pow2 = 1.0f;
     for (uint32_t k = 0; k < iteration; k++) pow2 *= 2.0f;
     const float threshold = spatial_threshold * sqrtf(pow2);
+    // The sweep itself only decides the topology (it needs nothing but the collector weights): the children of a split
+    // are exact copies of their parent's quadtrees (collector weight halved), so the copies — most of the work — are
+    // left to the parallel pass below; a leaf created here remembers which node still holds the data it descends from.
     for (size_t i = 0; i < nodes.size(); i++) {
         if (nodes[i].left != 0 || !(nodes[i].collector.weight > threshold)) continue;
         const uint32_t l = (uint32_t)nodes.size(), r = l + 1;
-        HostSNode a, b;
-        a.sampler = nodes[i].sampler;
-        a.collector = nodes[i].collector;
-        b.sampler = std::move(nodes[i].sampler);
-        b.collector = std::move(nodes[i].collector);
-        nodes[i].sampler = HostDTree{};
-        nodes[i].collector = HostDTree{};
-        a.axis = b.axis = (nodes[i].axis + 1) % 3;
-        a.depth = b.depth = nodes[i].depth + 1;
-        a.collector.weight /= 2.0f;
-        b.collector.weight /= 2.0f;
+        HostSNode a;
+        a.tree_source = nodes[i].tree_source >= 0 ? nodes[i].tree_source : (int64_t)i;
+        a.axis = (nodes[i].axis + 1) % 3;
+        a.depth = nodes[i].depth + 1;
+        a.sampler.weight = nodes[i].sampler.weight;
+        a.collector.weight = nodes[i].collector.weight / 2.0f;
+        HostSNode b = a;
         nodes[i].left = l;
         nodes[i].right = r;
         nodes.push_back(std::move(a));
         nodes.push_back(std::move(b));
     }
+    static const bool trace = getenv("PTGPU_TRACE") != nullptr;
+    const auto t_split = std::chrono::steady_clock::now();
     // STreeNode::subdivide_dtree for every leaf (stree.rs:49-53,255-260)
     std::atomic<bool> ok{true};
     parallel_for(nodes.size(), 16, [&](size_t i) {
         HostSNode& n = nodes[i];
         if (n.left != 0) return;
+        if (n.tree_source >= 0) {  // split off this iteration: take the ancestor's quadtrees (it is interior now, nobody writes it)
+            const HostSNode& src = nodes[(size_t)n.tree_source];  // (its sampler is not needed: emit_into below replaces it)
+            n.collector.nodes = src.collector.nodes;
+            n.collector.free_slots = src.collector.free_slots;
+        }
         rebuild_sums(n.collector, 0);
         n.sampler.weight = n.collector.weight;  // emit_into (dtree.rs:325-328)
         n.sampler.nodes = n.collector.nodes;
         n.sampler.free_slots = n.collector.free_slots;
         if (!refine_directional(n.collector, directional_threshold)) ok = false;
     });
+    // interior nodes that served as copy sources give their quadtrees back
+    parallel_for(nodes.size(), 64, [&](size_t i) {
+        HostSNode& n = nodes[i];
+        n.tree_source = -1;
+        if (n.left != 0 && !n.sampler.nodes.empty()) {
+            n.sampler = HostDTree{};
+            n.collector = HostDTree{};
+        }
+    });
+    if (trace)
+        fprintf(stderr, "[ptgpu]   refine: spatial split %.2f ms (serial), directional %.2f ms (parallel)\n",
+                std::chrono::duration<double, std::milli>(t_split - t_begin).count(),
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_split).count());
     if (!ok) {
         if (err) *err = "a directional quadtree needs more than 65535 nodes (u16 child links)";
         return false;

@@ -63,6 +63,7 @@ struct HostSNode {  // STreeNode (stree.rs:12-19)
     HostDTree sampler, collector;
     uint32_t left = 0, right = 0;  // 0 = leaf
     uint32_t axis = 0, depth = 0;
+    int64_t tree_source = -1;  // during new_iteration: node whose quadtrees a freshly split leaf still has to copy
 };
 
 // Flat device image of the tree (see pt_guided.h for how the kernels read it).
