@@ -105,10 +105,18 @@ PT_D void store_spec(float4* a, float4* b, uint32_t i, const Spec& s) {
 }
 
 // SamplePixel::add / SplatPixel::add (camera.rs:138-146): f64 RGB accumulation, hardware f64 atomics.
+// Device film: kFilmStride doubles per pixel (RGB + one pad) so that a pixel never straddles a 64-byte atomic request;
+// the C ABI hands out packed RGB (k_pack_film).
+constexpr uint32_t kFilmStride = 4;
 PT_D void film_add_rgb(double* film, uint32_t pixel, const double rgb[3]) {
-    unsafeAtomicAdd(film + 3 * (size_t)pixel + 0, rgb[0]);
-    unsafeAtomicAdd(film + 3 * (size_t)pixel + 1, rgb[1]);
-    unsafeAtomicAdd(film + 3 * (size_t)pixel + 2, rgb[2]);
+    unsafeAtomicAdd(film + kFilmStride * (size_t)pixel + 0, rgb[0]);
+    unsafeAtomicAdd(film + kFilmStride * (size_t)pixel + 1, rgb[1]);
+    unsafeAtomicAdd(film + kFilmStride * (size_t)pixel + 2, rgb[2]);
+}
+__global__ __launch_bounds__(kBlock) void k_pack_film(const double* film, double* rgb_out, uint32_t n_pixels) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 3 * n_pixels) return;
+    rgb_out[i] = film[kFilmStride * (size_t)(i / 3u) + i % 3u];
 }
 // The Film add issued by the whole wave (every lane must get here; `want` marks the lanes with something to add).
 // Float atomics run at the memory side at a fixed rate of 64-byte requests (MI355X_MICROARCH.md "Global float
@@ -124,7 +132,7 @@ PT_D void film_add_rgb_wave(double* film, uint32_t pixel, const double rgb[3], b
         const uint32_t px = (uint32_t)__shfl((int)pixel, (int)src);
         const int w = __shfl(want ? 1 : 0, (int)src);
         const double v0 = __shfl(rgb[0], (int)src), v1 = __shfl(rgb[1], (int)src), v2 = __shfl(rgb[2], (int)src);
-        if (w) unsafeAtomicAdd(film + 3 * (size_t)px + c, c == 0u ? v0 : (c == 1u ? v1 : v2));
+        if (w) unsafeAtomicAdd(film + kFilmStride * (size_t)px + c, c == 0u ? v0 : (c == 1u ? v1 : v2));
     }
 }
 PT_D void film_add_wave(const SceneDev& sc, double* film, const float4* lambda_tab, uint32_t row, uint32_t pixel, const Spec& l, bool sec_term, bool want) {
@@ -143,7 +151,7 @@ struct RenderParams {
     uint32_t resx;           // image width (pixel index = x + y*resx)
     const float4* lambda_tab;  // per wavelength-table entry: 8 lambdas + 8 pdfs (see ptgpu.hip: wavelength tables)
     SpecTab spec;            // the scene's spectra at every table entry's wavelengths
-    double* film;            // resx*resy*3
+    double* film;            // resx*resy*kFilmStride
 };
 
 __global__ __launch_bounds__(kBlock) void k_build_lambda_table(const float* u, float4* tab, uint32_t n) {

@@ -125,7 +125,8 @@ struct ptgpu_ctx {
     DevBuf<uint2> d_hit_prim;
     DevBuf<float4> d_shadow;  // q0 | q1 | q2,q3 contiguous (4 * capacity)
     DevBuf<RoundCounters> d_counters;
-    DevBuf<double> d_film;
+    DevBuf<double> d_film;         // kFilmStride doubles per pixel
+    DevBuf<double> d_film_packed;  // RGB, what the ABI returns
     DevBuf<float> d_lambda_u;
     DevBuf<float4> d_spec_tab;
     SpecTab spec{nullptr, 0, 0};
@@ -729,7 +730,11 @@ int check_render_args(ptgpu_ctx* c, const ptgpu_integrator_desc* integ, uint32_t
 
 int download_film(ptgpu_ctx* c, double* film_out) {
     if (film_out) {
-        HIP_TRY(hipMemcpyAsync(film_out, c->d_film.p, c->d_film.n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        const uint32_t npix = c->camera.resx * c->camera.resy;
+        HIP_TRY(c->d_film_packed.reserve(3 * (size_t)npix));
+        hipLaunchKernelGGL(k_pack_film, dim3((3 * npix + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, c->d_film.p, c->d_film_packed.p, npix);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(film_out, c->d_film_packed.p, 3 * (size_t)npix * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
     return PTGPU_OK;
@@ -750,7 +755,7 @@ int ptgpu_render_shard(ptgpu_ctx* c, const ptgpu_integrator_desc* integ, uint32_
     if (stats) memset(stats, 0, sizeof(*stats));
     reset_stage_times(c);
     const auto t0 = std::chrono::steady_clock::now();
-    const size_t film_n = (size_t)c->camera.resx * c->camera.resy * 3;
+    const size_t film_n = (size_t)c->camera.resx * c->camera.resy * kFilmStride;
     if (c->d_film.n != film_n) HIP_TRY(c->d_film.alloc(film_n));
     if (integ->kind == PTGPU_INTEGRATOR_GUIDED) {
         uint32_t n_waves = 0;
