@@ -113,11 +113,19 @@ PT_D void film_add_rgb(double* film, uint32_t pixel, const double rgb[3]) {
     unsafeAtomicAdd(film + kFilmStride * (size_t)pixel + 1, rgb[1]);
     unsafeAtomicAdd(film + kFilmStride * (size_t)pixel + 2, rgb[2]);
 }
-__global__ __launch_bounds__(kBlock) void k_pack_film(const double* film, double* rgb_out, uint32_t n_pixels) {
+// `n_copies` private films (light tracing, below) are summed in a fixed order.
+__global__ __launch_bounds__(kBlock) void k_pack_film(const double* film, double* rgb_out, uint32_t n_pixels, uint32_t n_copies) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= 3 * n_pixels) return;
-    rgb_out[i] = film[kFilmStride * (size_t)(i / 3u) + i % 3u];
+    const size_t at = kFilmStride * (size_t)(i / 3u) + i % 3u;
+    double v = film[at];
+    for (uint32_t k = 1; k < n_copies; k++) v += film[at + (size_t)k * kFilmStride * n_pixels];
+    rgb_out[i] = v;
 }
+// Light tracing connects every path's first vertex — a point ON the light — to the camera, so a few thousand pixels
+// (the light's image) receive one splat per path each: same-address atomics serialise at the memory side and that
+// contention, not the ray casting, set k_occlude_splat's time. kLightFilms private films, picked by workgroup, divide it.
+constexpr uint32_t kLightFilms = 16;
 // The Film add issued by the whole wave (every lane must get here; `want` marks the lanes with something to add).
 // Float atomics run at the memory side at a fixed rate of 64-byte requests (MI355X_MICROARCH.md "Global float
 // atomics"): one lane per pixel makes three instructions of 64 single-double requests each; dealing the three
@@ -149,9 +157,11 @@ struct RenderParams {
     int mode;
     uint32_t capacity;       // slots per state set
     uint32_t resx;           // image width (pixel index = x + y*resx)
+    uint32_t n_pixels;
     const float4* lambda_tab;  // per wavelength-table entry: 8 lambdas + 8 pdfs (see ptgpu.hip: wavelength tables)
     SpecTab spec;            // the scene's spectra at every table entry's wavelengths
     double* film;            // resx*resy*kFilmStride
+    uint32_t film_copies;    // 1, or kLightFilms private films back to back (lightpath)
 };
 
 __global__ __launch_bounds__(kBlock) void k_build_lambda_table(const float* u, float4* tab, uint32_t n) {
@@ -635,7 +645,7 @@ __global__ __launch_bounds__(kBlock) void k_occlude_splat(SceneDev sc, RenderPar
                 visible = true;
             }
         }
-        film_add_rgb_wave(rp.film, pixel, rgb, visible);
+        film_add_rgb_wave(rp.film + (size_t)(blockIdx.x % rp.film_copies) * kFilmStride * rp.n_pixels, pixel, rgb, visible);
     }
     if (CENSUS) census_add(census, 2, cn, ct);
 }

@@ -125,7 +125,8 @@ struct ptgpu_ctx {
     DevBuf<uint2> d_hit_prim;
     DevBuf<float4> d_shadow;  // q0 | q1 | q2,q3 contiguous (4 * capacity)
     DevBuf<RoundCounters> d_counters;
-    DevBuf<double> d_film;         // kFilmStride doubles per pixel
+    DevBuf<double> d_film;         // kFilmStride doubles per pixel, film_copies films back to back
+    uint32_t film_copies = 1;
     DevBuf<double> d_film_packed;  // RGB, what the ABI returns
     DevBuf<float> d_lambda_u;
     DevBuf<float4> d_spec_tab;
@@ -709,6 +710,8 @@ int render_path_like(ptgpu_ctx* c, const ptgpu_integrator_desc* integ, uint32_t 
     rp.lambda_tab = c->d_lambda_tab.p;
     rp.spec = c->spec;
     rp.film = c->d_film.p;
+    rp.film_copies = c->film_copies;
+    rp.n_pixels = (uint32_t)npix;
     const uint64_t passes_per_batch = c->capacity / npix;
     for (uint64_t done = 0; done < my_samples; done += passes_per_batch) {
         const uint64_t passes = std::min(passes_per_batch, my_samples - done);
@@ -732,7 +735,7 @@ int download_film(ptgpu_ctx* c, double* film_out) {
     if (film_out) {
         const uint32_t npix = c->camera.resx * c->camera.resy;
         HIP_TRY(c->d_film_packed.reserve(3 * (size_t)npix));
-        hipLaunchKernelGGL(k_pack_film, dim3((3 * npix + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, c->d_film.p, c->d_film_packed.p, npix);
+        hipLaunchKernelGGL(k_pack_film, dim3((3 * npix + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, c->d_film.p, c->d_film_packed.p, npix, c->film_copies);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(film_out, c->d_film_packed.p, 3 * (size_t)npix * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     }
@@ -755,7 +758,8 @@ int ptgpu_render_shard(ptgpu_ctx* c, const ptgpu_integrator_desc* integ, uint32_
     if (stats) memset(stats, 0, sizeof(*stats));
     reset_stage_times(c);
     const auto t0 = std::chrono::steady_clock::now();
-    const size_t film_n = (size_t)c->camera.resx * c->camera.resy * kFilmStride;
+    c->film_copies = integ->kind == PTGPU_INTEGRATOR_LIGHTPATH ? kLightFilms : 1;
+    const size_t film_n = (size_t)c->camera.resx * c->camera.resy * kFilmStride * c->film_copies;
     if (c->d_film.n != film_n) HIP_TRY(c->d_film.alloc(film_n));
     if (integ->kind == PTGPU_INTEGRATOR_GUIDED) {
         uint32_t n_waves = 0;
