@@ -50,6 +50,10 @@ struct SdTreeDev {
     float4* c_rad;
     const uint2* c_child;
     float* c_weight;
+    float* w_private;     // kWeightCopies x n_leaves: record counts per leaf, one copy per group of workgroups (folded into
+                          // c_weight by k_fold_weights when the wave is done) — every record bumps its leaf's count, and
+                          // same-address atomics serialise at the memory side
+    uint32_t n_leaves;
     V3 blo, bhi;
     uint32_t iteration;  // Guider::iteration: 0 = no guiding yet
 };
@@ -147,6 +151,7 @@ PT_HD int cell_child_of(Cell c, V2 p, Cell& out) {  // child_index (dtree.rs:331
     return r;
 }
 constexpr uint32_t kMaxQuadLevel = 24;
+constexpr uint32_t kWeightCopies = 16;
 
 // DTree::sample (dtree.rs:98-153): one float per level, two at the leaf.
 PT_D V2 dtree_sample(const SdTreeDev& t, uint4 leaf, Rng& rng) {
@@ -323,7 +328,7 @@ PT_D void dtree_record_box(const SdTreeDev& t, uint32_t leaf_id, uint4 leaf, V2 
     Box2 fp{{0.0f, 0.0f}, {0.0f, 0.0f}};
     float fp_area = 0.0f;
     if (active) {
-        unsafeAtomicAdd(t.c_weight + leaf_id, 1.0f);
+        unsafeAtomicAdd(t.w_private + (size_t)(blockIdx.x % kWeightCopies) * t.n_leaves + leaf_id, 1.0f);
         // DTree::leaf (dtree.rs:81-94): the cell that holds p
         Cell cell{0, 0, 0};
         uint32_t ni = 0;
@@ -730,6 +735,15 @@ __global__ __launch_bounds__(kBlock) void k_guide_scan(SceneDev sc, RenderParams
         __syncthreads();
         if (threadIdx.x == 0) rq.count[chunk] = sm_n;
     }
+}
+
+// c_weight[l] += the private counts of leaf l (whole numbers: the order of the sum does not matter).
+__global__ __launch_bounds__(kBlock) void k_fold_weights(SdTreeDev tree) {
+    const uint32_t l = blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= tree.n_leaves) return;
+    float w = tree.c_weight[l];
+    for (uint32_t k = 0; k < kWeightCopies; k++) w += tree.w_private[(size_t)k * tree.n_leaves + l];
+    tree.c_weight[l] = w;
 }
 
 // STree::record with the stochastic spatial filter (stree.rs:102-116,186-201) for the queued records.
