@@ -313,12 +313,39 @@ PT_D bool guider_sample(const SdTreeDev& t, const Bsdf& bsdf, const Frame& fr, V
 // leaf cell the footprint (a box of the size of the cell containing p, centred on p, clipped to the unit square)
 // overlaps, in proportion to the overlap. f32 atomics straight into HBM.
 //
-// Called by the WHOLE wave (`active` marks lanes that carry a record). Float atomics cost one memory-side request per
-// 64-byte line per wave instruction, so the four child sums of a node (16 contiguous bytes) are not added by the lane
-// that computed them, one instruction per child, but by the four lanes of its quad in one instruction: the quad takes
-// its members' nodes in turn, lane j adding child j's share. A footprint that covers sibling cells then costs one
-// request instead of up to four.
-PT_D void dtree_record_box(const SdTreeDev& t, uint32_t leaf_id, uint4 leaf, V2 p, float radiance, bool active) {
+// Called by the WHOLE wave (`active` marks lanes that carry a record). What bounds this kernel is the memory-side
+// float atomic path, in two currencies (MI355X_MICROARCH.md "Global float atomics"): 64-byte REQUESTS chip-wide and
+// atomic wave-INSTRUCTIONS per CU (one per ~50 ns, however few lanes it carries). So
+//  * the four child sums of a node (16 contiguous bytes) are added by the four lanes of a quad in one instruction —
+//    the quad takes its members' nodes in turn, lane j adding child j's share: sibling cells cost one request;
+//  * the adds are not issued as the walk finds them (every step of every lane would cost the wave four sparse
+//    instructions) but parked per lane in LDS (node, four shares) and flushed when the walk is over, entry k of all
+//    lanes together: 4 x (the largest number of touched nodes in the wave) instructions per record instead of
+//    4 x (the longest walk).
+constexpr uint32_t kSplatPending = 6;                       // parked (node, shares) entries per lane
+constexpr uint32_t kSplatPendingWords = 5 * kSplatPending;  // LDS dwords per lane: [entry][field][lane]
+PT_D void splat_flush(const SdTreeDev& t, uint32_t* pend, uint32_t& n_pend) {
+    const uint32_t lane = __lane_id(), quad_base = lane & ~3u, me = lane & 3u;
+    uint32_t most = n_pend;
+    for (int off = 32; off > 0; off >>= 1) most = max(most, (uint32_t)__shfl_xor((int)most, off));
+    for (uint32_t k = 0; k < most; k++) {
+        const bool have = k < n_pend;
+        const uint32_t node = have ? pend[(5 * k) * kBlock] : 0u;
+        float share[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) share[c] = have ? u2f(pend[(5 * k + 1 + c) * kBlock]) : 0.0f;
+#pragma unroll
+        for (uint32_t r = 0; r < 4; r++) {
+            const int src = (int)(quad_base + r);
+            const uint32_t node_r = (uint32_t)__shfl((int)node, src);
+            const float s0 = __shfl(share[0], src), s1 = __shfl(share[1], src), s2 = __shfl(share[2], src), s3 = __shfl(share[3], src);
+            const float mine = me == 0u ? s0 : (me == 1u ? s1 : (me == 2u ? s2 : s3));
+            if (mine != 0.0f) unsafeAtomicAdd(reinterpret_cast<float*>(t.c_rad + node_r) + me, mine);
+        }
+    }
+    n_pend = 0;
+}
+PT_D void dtree_record_box(const SdTreeDev& t, uint32_t leaf_id, uint4 leaf, V2 p, float radiance, bool active, uint32_t* pend) {
     struct Item {
         uint32_t node;
         Cell cell;
@@ -346,14 +373,12 @@ PT_D void dtree_record_box(const SdTreeDev& t, uint32_t leaf_id, uint4 leaf, V2 
         fp_area = box2_area(fp);
         stack[sp++] = Item{0, Cell{0, 0, 0}};
     }
-    const uint32_t lane = __lane_id(), quad_base = lane & ~3u, me = lane & 3u;
+    uint32_t n_pend = 0;
     // depth-first over (node, cell) pairs; children visited in index order like the recursion
-    while (__ballot(sp > 0) != 0ull) {
-        float share[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-        uint32_t node_index = 0;  // arena index of the node whose children get `share`
-        if (sp > 0) {
+    for (;;) {
+        while (sp > 0 && n_pend < kSplatPending) {
             const Item it = stack[--sp];
-            node_index = leaf.y + it.node;
+            const uint32_t node_index = leaf.y + it.node;
             const uint2 links = t.c_child[node_index];
             // The four children share three x and three y coordinates, so the overlap with the footprint is two 1-D
             // extents per axis; the values are those of Bounds2::overlap on cell_box(child) (same operands, same order).
@@ -362,6 +387,8 @@ PT_D void dtree_record_box(const SdTreeDev& t, uint32_t leaf_id, uint4 leaf, V2 
             const float y0 = (float)(2 * it.cell.iy) * cs, ym = (float)(2 * it.cell.iy + 1) * cs, y1 = (float)(2 * it.cell.iy + 2) * cs;
             const float ex[2] = {fminf(fp.hi.x, xm) - fmaxf(fp.lo.x, x0), fminf(fp.hi.x, x1) - fmaxf(fp.lo.x, xm)};
             const float ey[2] = {fminf(fp.hi.y, ym) - fmaxf(fp.lo.y, y0), fminf(fp.hi.y, y1) - fmaxf(fp.lo.y, ym)};
+            float share[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            bool any = false;
 #pragma unroll
             for (int c = 3; c >= 0; c--) {  // pushed in reverse so that child 0 is expanded first
                 const float ox = ex[c & 1], oy = ey[c >> 1];
@@ -370,25 +397,27 @@ PT_D void dtree_record_box(const SdTreeDev& t, uint32_t leaf_id, uint4 leaf, V2 
                 if (w == 0.0f || !(w == w)) continue;
                 const uint32_t link = child_link(links, c);
                 const uint32_t child_level = it.cell.level + 1;
-                if (link == 0 || child_level >= kMaxQuadLevel) share[c] = radiance * w;
-                else if (sp < (int)(sizeof(stack) / sizeof(stack[0])))
+                if (link == 0 || child_level >= kMaxQuadLevel) {
+                    share[c] = radiance * w;
+                    any = true;
+                } else if (sp < (int)(sizeof(stack) / sizeof(stack[0])))
                     stack[sp++] = Item{link, Cell{2 * it.cell.ix + (uint32_t)(c & 1), 2 * it.cell.iy + (uint32_t)(c >> 1), child_level}};
             }
-        }
+            if (any) {
+                pend[(5 * n_pend) * kBlock] = node_index;
 #pragma unroll
-        for (uint32_t r = 0; r < 4; r++) {
-            const int src = (int)(quad_base + r);
-            const uint32_t node_r = (uint32_t)__shfl((int)node_index, src);
-            const float s0 = __shfl(share[0], src), s1 = __shfl(share[1], src), s2 = __shfl(share[2], src), s3 = __shfl(share[3], src);
-            const float mine = me == 0u ? s0 : (me == 1u ? s1 : (me == 2u ? s2 : s3));
-            if (mine != 0.0f) unsafeAtomicAdd(reinterpret_cast<float*>(t.c_rad + node_r) + me, mine);
+                for (int c = 0; c < 4; c++) pend[(5 * n_pend + 1 + c) * kBlock] = f2u(share[c]);
+                n_pend++;
+            }
         }
+        splat_flush(t, pend, n_pend);  // whole wave
+        if (__ballot(sp > 0) == 0ull) break;
     }
 }
 
 // STree::record with the stochastic spatial filter (stree.rs:102-116,186-201); the caller has checked that
 // `radiance` is finite and non-zero and has drawn the three jitter numbers.
-PT_D void stree_record_jittered(const SdTreeDev& t, V3 p, V3 wi, float radiance, float u0, float u1, float u2, bool active) {
+PT_D void stree_record_jittered(const SdTreeDev& t, V3 p, V3 wi, float radiance, float u0, float u1, float u2, bool active, uint32_t* pend) {
     V2 p2 = V2{0.0f, 0.0f};
     uint32_t leaf_id = 0;
     uint4 leaf = make_uint4(0, 0, 0, 0);
@@ -403,7 +432,7 @@ PT_D void stree_record_jittered(const SdTreeDev& t, V3 p, V3 wi, float radiance,
         leaf_id = stree_leaf<false>(t, q, lo, hi);
         leaf = t.leaf_info[leaf_id];
     }
-    dtree_record_box(t, leaf_id, leaf, p2, radiance, active);  // wave-cooperative
+    dtree_record_box(t, leaf_id, leaf, p2, radiance, active, pend);  // wave-cooperative
 }
 
 struct GuidedParams {
@@ -748,6 +777,7 @@ __global__ __launch_bounds__(kBlock) void k_fold_weights(SdTreeDev tree) {
 
 // STree::record with the stochastic spatial filter (stree.rs:102-116,186-201) for the queued records.
 __global__ __launch_bounds__(kBlock) void k_guide_splat(SdTreeDev tree, GuidedParams gp, RecordQueue rq, uint32_t n_paths) {
+    __shared__ uint32_t sm_pend[kSplatPendingWords * kBlock];
     const uint32_t n_chunks = (n_paths + kBlock - 1) / kBlock;
     for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
         const uint32_t n = rq.count[chunk];
@@ -762,7 +792,7 @@ __global__ __launch_bounds__(kBlock) void k_guide_splat(SdTreeDev tree, GuidedPa
                 b = rq.q1[base + j];
                 c = rq.q2[base + j];
             }
-            stree_record_jittered(tree, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), a.w, b.w, c.x, c.y, active);
+            stree_record_jittered(tree, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), a.w, b.w, c.x, c.y, active, sm_pend + threadIdx.x);
         }
     }
 }
