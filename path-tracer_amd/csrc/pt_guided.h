@@ -322,7 +322,8 @@ PT_D bool guider_sample(const SdTreeDev& t, const Bsdf& bsdf, const Frame& fr, V
 //    instructions) but parked per lane in LDS (node, four shares) and flushed when the walk is over, entry k of all
 //    lanes together: 4 x (the largest number of touched nodes in the wave) instructions per record instead of
 //    4 x (the longest walk).
-constexpr uint32_t kSplatPending = 6;                       // parked (node, shares) entries per lane
+constexpr uint32_t kSplatPending = 4;                       // parked (node, shares) entries per lane
+constexpr uint32_t kSplatStackLds = 8;                      // walk-stack entries kept in LDS (two dwords each); deeper ones spill to scratch
 constexpr uint32_t kSplatPendingWords = 5 * kSplatPending;  // LDS dwords per lane: [entry][field][lane]
 PT_D void splat_flush(const SdTreeDev& t, uint32_t* pend, uint32_t& n_pend) {
     const uint32_t lane = __lane_id(), quad_base = lane & ~3u, me = lane & 3u;
@@ -346,12 +347,30 @@ PT_D void splat_flush(const SdTreeDev& t, uint32_t* pend, uint32_t& n_pend) {
     n_pend = 0;
 }
 PT_D void dtree_record_box(const SdTreeDev& t, uint32_t leaf_id, uint4 leaf, V2 p, float radiance, bool active, uint32_t* pend) {
+    // Walk stack: (node, cell) packed in two dwords — node 16 bits | level 5 bits | ix, iy 21 bits each (levels above 21
+    // cannot be packed and are not pushed: the reference's trees stay far below) — the first kSplatStackLds entries
+    // in LDS, the rest in scratch.
     struct Item {
         uint32_t node;
         Cell cell;
     };
-    Item stack[3 * kMaxQuadLevel + 4];
+    uint2 deep[3 * kMaxQuadLevel + 4 - kSplatStackLds];
+    uint32_t* lds_stack = pend + kSplatPendingWords * kBlock;
     int sp = 0;
+    auto push = [&](const Item& it) {
+        const uint2 w = make_uint2(it.node | (it.cell.level << 16) | ((it.cell.ix & 0x7ffu) << 21), (it.cell.ix >> 11) | (it.cell.iy << 10));
+        if (sp < (int)kSplatStackLds) {
+            lds_stack[(2 * sp) * kBlock] = w.x;
+            lds_stack[(2 * sp + 1) * kBlock] = w.y;
+        } else
+            deep[sp - (int)kSplatStackLds] = w;
+        sp++;
+    };
+    auto pop = [&]() {
+        --sp;
+        const uint2 w = sp < (int)kSplatStackLds ? make_uint2(lds_stack[(2 * sp) * kBlock], lds_stack[(2 * sp + 1) * kBlock]) : deep[sp - (int)kSplatStackLds];
+        return Item{w.x & 0xffffu, Cell{((w.x >> 21) & 0x7ffu) | ((w.y & 0x3ffu) << 11), w.y >> 10, (w.x >> 16) & 31u}};
+    };
     Box2 fp{{0.0f, 0.0f}, {0.0f, 0.0f}};
     float fp_area = 0.0f;
     if (active) {
@@ -371,13 +390,13 @@ PT_D void dtree_record_box(const SdTreeDev& t, uint32_t leaf_id, uint4 leaf, V2 
         fp = box2_around(p, box2_extent(lb));
         fp = Box2{clamp2(V2{0.0f, 0.0f}, fp.lo, fp.hi), clamp2(V2{1.0f, 1.0f}, fp.lo, fp.hi)};  // Bounds2::clamp (bounds.rs:46-50)
         fp_area = box2_area(fp);
-        stack[sp++] = Item{0, Cell{0, 0, 0}};
+        push(Item{0, Cell{0, 0, 0}});
     }
     uint32_t n_pend = 0;
     // depth-first over (node, cell) pairs; children visited in index order like the recursion
     for (;;) {
         while (sp > 0 && n_pend < kSplatPending) {
-            const Item it = stack[--sp];
+            const Item it = pop();
             const uint32_t node_index = leaf.y + it.node;
             const uint2 links = t.c_child[node_index];
             // The four children share three x and three y coordinates, so the overlap with the footprint is two 1-D
@@ -400,8 +419,8 @@ PT_D void dtree_record_box(const SdTreeDev& t, uint32_t leaf_id, uint4 leaf, V2 
                 if (link == 0 || child_level >= kMaxQuadLevel) {
                     share[c] = radiance * w;
                     any = true;
-                } else if (sp < (int)(sizeof(stack) / sizeof(stack[0])))
-                    stack[sp++] = Item{link, Cell{2 * it.cell.ix + (uint32_t)(c & 1), 2 * it.cell.iy + (uint32_t)(c >> 1), child_level}};
+                } else if (sp < (int)(3 * kMaxQuadLevel + 4) && child_level <= 21u)
+                    push(Item{link, Cell{2 * it.cell.ix + (uint32_t)(c & 1), 2 * it.cell.iy + (uint32_t)(c >> 1), child_level}});
             }
             if (any) {
                 pend[(5 * n_pend) * kBlock] = node_index;
@@ -777,7 +796,7 @@ __global__ __launch_bounds__(kBlock) void k_fold_weights(SdTreeDev tree) {
 
 // STree::record with the stochastic spatial filter (stree.rs:102-116,186-201) for the queued records.
 __global__ __launch_bounds__(kBlock) void k_guide_splat(SdTreeDev tree, GuidedParams gp, RecordQueue rq, uint32_t n_paths) {
-    __shared__ uint32_t sm_pend[kSplatPendingWords * kBlock];
+    __shared__ uint32_t sm_pend[(kSplatPendingWords + 2 * kSplatStackLds) * kBlock];  // parked adds, then the walk stack
     const uint32_t n_chunks = (n_paths + kBlock - 1) / kBlock;
     for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
         const uint32_t n = rq.count[chunk];
