@@ -347,9 +347,9 @@ PT_D void splat_flush(const SdTreeDev& t, uint32_t* pend, uint32_t& n_pend) {
     n_pend = 0;
 }
 PT_D void dtree_record_box(const SdTreeDev& t, uint32_t leaf_id, uint4 leaf, V2 p, float radiance, bool active, uint32_t* pend) {
-    // Walk stack: (node, cell) packed in two dwords — node 16 bits | level 5 bits | ix, iy 21 bits each (levels above 21
-    // cannot be packed and are not pushed: the reference's trees stay far below) — the first kSplatStackLds entries
-    // in LDS, the rest in scratch.
+    // Walk stack: (node, cell) packed in two dwords — node 16 bits, iy 23 bits, and ix behind a leading 1 whose position
+    // is the level (24 bits): every cell that can be pushed (level < kMaxQuadLevel = 24) fits. The first kSplatStackLds
+    // entries live in LDS, the rest in scratch.
     struct Item {
         uint32_t node;
         Cell cell;
@@ -358,7 +358,7 @@ PT_D void dtree_record_box(const SdTreeDev& t, uint32_t leaf_id, uint4 leaf, V2 
     uint32_t* lds_stack = pend + kSplatPendingWords * kBlock;
     int sp = 0;
     auto push = [&](const Item& it) {
-        const uint2 w = make_uint2(it.node | (it.cell.level << 16) | ((it.cell.ix & 0x7ffu) << 21), (it.cell.ix >> 11) | (it.cell.iy << 10));
+        const uint2 w = make_uint2(it.node | (it.cell.iy << 16), ((1u << it.cell.level) | it.cell.ix) | ((it.cell.iy >> 16) << 24));
         if (sp < (int)kSplatStackLds) {
             lds_stack[(2 * sp) * kBlock] = w.x;
             lds_stack[(2 * sp + 1) * kBlock] = w.y;
@@ -369,7 +369,8 @@ PT_D void dtree_record_box(const SdTreeDev& t, uint32_t leaf_id, uint4 leaf, V2 
     auto pop = [&]() {
         --sp;
         const uint2 w = sp < (int)kSplatStackLds ? make_uint2(lds_stack[(2 * sp) * kBlock], lds_stack[(2 * sp + 1) * kBlock]) : deep[sp - (int)kSplatStackLds];
-        return Item{w.x & 0xffffu, Cell{((w.x >> 21) & 0x7ffu) | ((w.y & 0x3ffu) << 11), w.y >> 10, (w.x >> 16) & 31u}};
+        const uint32_t sx = w.y & 0xffffffu, level = 31u - (uint32_t)__clz((int)sx);
+        return Item{w.x & 0xffffu, Cell{sx ^ (1u << level), (w.x >> 16) | ((w.y >> 24) << 16), level}};
     };
     Box2 fp{{0.0f, 0.0f}, {0.0f, 0.0f}};
     float fp_area = 0.0f;
@@ -419,7 +420,7 @@ PT_D void dtree_record_box(const SdTreeDev& t, uint32_t leaf_id, uint4 leaf, V2 
                 if (link == 0 || child_level >= kMaxQuadLevel) {
                     share[c] = radiance * w;
                     any = true;
-                } else if (sp < (int)(3 * kMaxQuadLevel + 4) && child_level <= 21u)
+                } else if (sp < (int)(3 * kMaxQuadLevel + 4))
                     push(Item{link, Cell{2 * it.cell.ix + (uint32_t)(c & 1), 2 * it.cell.iy + (uint32_t)(c >> 1), child_level}});
             }
             if (any) {
