@@ -360,7 +360,9 @@ PT_D Hit bvh_intersect(const SceneDev& sc, V3 o, V3 d, float ray_end_t, uint32_t
     best.th.b0 = best.th.b1 = best.th.b2 = 0.0f;
     const V3 inv = splat(1.0f) / d;
     const bool nx = inv.x < 0.0f, ny = inv.y < 0.0f, nz = inv.z < 0.0f;
+    const uint32_t neg_mask = (nx ? 1u : 0u) | (ny ? 2u : 0u) | (nz ? 4u : 0u);
     const float slack = 1.0f + 2.0f * gamma_n(3.0f);
+    const V3 sinv = mk3(slack * inv.x, slack * inv.y, slack * inv.z);  // the reference's `slack * inv * (far - o)` associates this way
     const RayShear shear = ray_shear(d);
     uint32_t* pend = sm_bvh_stack + sc.bvh_stack * kBlock + threadIdx.x;  // leaves waiting for their triangle tests
     uint32_t sp = 0;
@@ -370,31 +372,30 @@ PT_D Hit bvh_intersect(const SceneDev& sc, V3 o, V3 d, float ray_end_t, uint32_t
         uint32_t n_pend = 0;
         while (have_node && n_pend < kLeafQueue) {
             const float4 n0 = sc.nodes[2 * ni], n1 = sc.nodes[2 * ni + 1];
+            const uint32_t offset = f2u(n0.w), meta = f2u(n1.w);
             if (COUNT) (*n_nodes_visited)++;
             float tmin = 0.0f, tmax = ray_end_t;
             {
                 float near_x = nx ? n1.x : n0.x, far_x = nx ? n0.x : n1.x;
                 float t0 = inv.x * (near_x - o.x);
-                float t1 = slack * inv.x * (far_x - o.x);
+                float t1 = sinv.x * (far_x - o.x);
                 tmin = fmaxf(tmin, t0);
                 tmax = fminf(tmax, t1);
                 float near_y = ny ? n1.y : n0.y, far_y = ny ? n0.y : n1.y;
                 t0 = inv.y * (near_y - o.y);
-                t1 = slack * inv.y * (far_y - o.y);
+                t1 = sinv.y * (far_y - o.y);
                 tmin = fmaxf(tmin, t0);
                 tmax = fminf(tmax, t1);
                 float near_z = nz ? n1.z : n0.z, far_z = nz ? n0.z : n1.z;
                 t0 = inv.z * (near_z - o.z);
-                t1 = slack * inv.z * (far_z - o.z);
+                t1 = sinv.z * (far_z - o.z);
                 tmin = fmaxf(tmin, t0);
                 tmax = fminf(tmax, t1);
             }
             if ((0.0f <= tmin) && (tmin <= tmax)) {
-                const uint32_t offset = f2u(n0.w), meta = f2u(n1.w);
                 const uint32_t ntris = meta & 0xffffu;
                 if (ntris == 0) {
-                    const uint32_t axis = meta >> 16;
-                    const bool neg = axis == 0 ? nx : (axis == 1 ? ny : nz);
+                    const bool neg = ((neg_mask >> (meta >> 16)) & 1u) != 0u;
                     if (sp < sc.bvh_stack) {  // holds for every tree scene_create accepts
                         stack[sp * kBlock] = neg ? ni + 1 : offset;  // far child waits
                         sp++;

@@ -223,7 +223,7 @@ __global__ __launch_bounds__(kBlock) void k_raygen_camera(SceneDev sc, CameraDev
 // ------------------------------------------------------------------ extend (closest hit)
 // Scene::intersect -> Bvh::intersect (scene.rs:184-186, bvh.rs:86-142) for slots [0, n_active).
 template <bool CENSUS>
-__global__ __launch_bounds__(kBlock) void k_extend(SceneDev sc, PathCols st, HitCols hit, const RoundCounters* cnt, unsigned long long* census) {
+__global__ __launch_bounds__(kBlock, 8) void k_extend(SceneDev sc, PathCols st, HitCols hit, const RoundCounters* cnt, unsigned long long* census) {
     const uint32_t n = cnt->n_active;
     const uint32_t stride = gridDim.x * blockDim.x;
     uint32_t cn = 0, ct = 0;
