@@ -431,7 +431,7 @@ __global__ __launch_bounds__(kBlock, PT_SHADE_WAVES) void k_shade_path(SceneDev 
 // Scene::occluded for the NEE shadow rays of this round; adds the MIS-weighted contribution to the path's
 // radiance and finishes paths that ended in shade with this ray still pending.
 template <bool CENSUS>
-__global__ __launch_bounds__(kBlock) void k_occlude_path(SceneDev sc, RenderParams rp, PathCols st, ShadowCols sh, const RoundCounters* cnt, unsigned long long* census) {
+__global__ __launch_bounds__(kBlock, 8) void k_occlude_path(SceneDev sc, RenderParams rp, PathCols st, ShadowCols sh, const RoundCounters* cnt, unsigned long long* census) {
     const uint32_t n = cnt->n_shadow;
     const uint32_t stride = gridDim.x * blockDim.x;
     uint32_t cn = 0, ct = 0;
