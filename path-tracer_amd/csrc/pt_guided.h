@@ -512,16 +512,23 @@ __global__ __launch_bounds__(kBlock) void k_raygen_guided(SceneDev sc, CameraDev
     }
 }
 
-PT_D void store_vertex(const GuidedParams& gp, uint32_t row, uint32_t pid, V3 p, V3 wi, float pdf, const Spec& f, const Spec& e) {
+// A stored vertex is written in two steps to keep registers free over the long sampling code in between: what is known
+// when the surface has been shaded (emitted light, the direct-light sample) goes into the vertex's row at once —
+// harmless if the vertex is not stored after all, the row stays beyond the path's count — the sampled direction
+// later. The direct-light sample is written as if visible; k_occlude_guided clears it when the shadow ray is blocked.
+PT_D void store_vertex_light(const GuidedParams& gp, uint32_t row, uint32_t pid, const Spec& e, const Spec& li) {
+    float4* v = gp.vtx.at(row, pid);
+    v[VTX_E0] = make_float4(e.v[0], e.v[1], e.v[2], e.v[3]);
+    v[VTX_E1] = make_float4(e.v[4], e.v[5], e.v[6], e.v[7]);
+    v[VTX_LI0] = make_float4(li.v[0], li.v[1], li.v[2], li.v[3]);
+    v[VTX_LI1] = make_float4(li.v[4], li.v[5], li.v[6], li.v[7]);
+}
+PT_D void store_vertex(const GuidedParams& gp, uint32_t row, uint32_t pid, V3 p, V3 wi, float pdf, const Spec& f) {
     float4* v = gp.vtx.at(row, pid);
     v[VTX_P_PDF] = make_float4(p.x, p.y, p.z, pdf);
     v[VTX_WI] = make_float4(wi.x, wi.y, wi.z, 0.0f);
     v[VTX_F0] = make_float4(f.v[0], f.v[1], f.v[2], f.v[3]);
     v[VTX_F1] = make_float4(f.v[4], f.v[5], f.v[6], f.v[7]);
-    v[VTX_E0] = make_float4(e.v[0], e.v[1], e.v[2], e.v[3]);
-    v[VTX_E1] = make_float4(e.v[4], e.v[5], e.v[6], e.v[7]);
-    v[VTX_LI0] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    v[VTX_LI1] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 }
 
 // One iteration of PathGuidingIntegrator::random_walk's loop body (mod.rs:139-278).
@@ -543,7 +550,7 @@ __global__ __launch_bounds__(kBlock, KINDS != 7 ? PT_GUIDED_DIFFUSE_WAVES : PT_S
         V3 o = mk3(0, 0, 0), d = mk3(0, 0, 1), prev_p = mk3(0, 0, 0), sh_from = mk3(0, 0, 0), sh_to = mk3(0, 0, 0);
         float prev_pdf = 0.0f;
         uint32_t flags = 0, pid = 0, nverts = 0, shadow_row = 0;
-        Spec beta = spec_splat(0.0f), contrib = spec_splat(0.0f);
+        Spec beta = spec_splat(0.0f);
         uint4 rp4 = make_uint4(0, 0, 0, 0);
         if (valid) {
             const float4 o4 = in.o_pdf[i], d4 = in.d_flags[i], pp = in.prev_p[i];
@@ -561,7 +568,8 @@ __global__ __launch_bounds__(kBlock, KINDS != 7 ? PT_GUIDED_DIFFUSE_WAVES : PT_S
             if (prim == kNoHit) {
                 // miss vertex (mod.rs:140-150): far point along the ray, nothing emitted without an envmap
                 if (nverts < gp.n_rows) {
-                    store_vertex(gp, nverts, pid, o + d * 10000.0f, d, 1.0f, spec_splat(1.0f), spec_splat(0.0f));
+                    store_vertex_light(gp, nverts, pid, spec_splat(0.0f), spec_splat(0.0f));
+                    store_vertex(gp, nverts, pid, o + d * 10000.0f, d, 1.0f, spec_splat(1.0f));
                     nverts++;
                 }
                 ended = true;
@@ -599,6 +607,7 @@ __global__ __launch_bounds__(kBlock, KINDS != 7 ? PT_GUIDED_DIFFUSE_WAVES : PT_S
                     Rng rng{(uint64_t)rp4.x | ((uint64_t)rp4.y << 32), rng_inc_for_pixel(rp4.z % rp.resx, rp4.z / rp.resx)};
                     PT_TICK(1);
                     bool has_nee = false;
+                    Spec contrib = spec_splat(0.0f);
                     if (rp.mode != MODE_PT && !specular) {
                         const float u1d = rng_f32(rng), ua = rng_f32(rng), ub = rng_f32(rng);
                         Tri lt;
@@ -623,6 +632,7 @@ __global__ __launch_bounds__(kBlock, KINDS != 7 ? PT_GUIDED_DIFFUSE_WAVES : PT_S
                             }
                         }
                     }
+                    if (!specular && nverts < gp.n_rows) store_vertex_light(gp, nverts, pid, emitted, contrib);
                     PT_TICK(2);
                     BsdfSample bs;
                     const bool ok = guider_sample(tree, bsdf, sf.frame, sf.ng, p, wo, rng, sm_scales + threadIdx.x, bs PT_DBG_ARGS);
@@ -640,7 +650,7 @@ __global__ __launch_bounds__(kBlock, KINDS != 7 ? PT_GUIDED_DIFFUSE_WAVES : PT_S
 #pragma unroll
                         for (int k = 0; k < NSW; k++) fw.v[k] = bs.f.v[k] / bs.pdf;
                         if (!specular && nverts < gp.n_rows) {
-                            store_vertex(gp, nverts, pid, p, bs.wi, bs.pdf, fw, emitted);
+                            store_vertex(gp, nverts, pid, p, bs.wi, bs.pdf, fw);
                             shadow_row = nverts;
                             want_shadow = has_nee;
                             nverts++;
@@ -684,7 +694,6 @@ __global__ __launch_bounds__(kBlock, KINDS != 7 ? PT_GUIDED_DIFFUSE_WAVES : PT_S
         if (want_shadow) {
             sh.q0[s_slot] = make_float4(sh_from.x, sh_from.y, sh_from.z, u2f(pid));
             sh.q1[s_slot] = make_float4(sh_to.x, sh_to.y, sh_to.z, u2f(shadow_row));
-            store_spec(sh.q2, sh.q3, s_slot, contrib);
         }
         PT_TICK(10);
     }
@@ -694,7 +703,7 @@ __global__ __launch_bounds__(kBlock, KINDS != 7 ? PT_GUIDED_DIFFUSE_WAVES : PT_S
     PT_TICK_FLUSH();
 }
 
-// NEE visibility for the guided walk: an unoccluded sample becomes the vertex's li_sample_contribution.
+// NEE visibility for the guided walk: shade wrote the sample into the vertex as if visible; a blocked one is cleared.
 template <bool CENSUS>
 __global__ __launch_bounds__(kBlock) void k_occlude_guided(SceneDev sc, GuidedParams gp, ShadowCols sh, const RoundCounters* cnt, unsigned long long* census) {
     const uint32_t n = cnt->n_shadow;
@@ -702,10 +711,10 @@ __global__ __launch_bounds__(kBlock) void k_occlude_guided(SceneDev sc, GuidedPa
     uint32_t cn = 0, ct = 0;
     for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) {
         const float4 a = sh.q0[j], b = sh.q1[j];
-        if (!scene_occluded<CENSUS>(sc, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), &cn, &ct)) {
+        if (scene_occluded<CENSUS>(sc, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), &cn, &ct)) {
             float4* v = gp.vtx.at(f2u(b.w), f2u(a.w));
-            v[VTX_LI0] = sh.q2[j];
-            v[VTX_LI1] = sh.q3[j];
+            v[VTX_LI0] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            v[VTX_LI1] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         }
     }
     if (CENSUS) census_add(census, 2, cn, ct);
