@@ -125,100 +125,87 @@ inline uint2 pack_children(const HostDNode& n) {
 void HostSdTree::init(V3 lo, V3 hi) {
     nodes.clear();
     nodes.emplace_back();
-    nodes[0].sampler.reset_root();
     nodes[0].collector.reset_root();
     const Box3 scene{lo, hi};
     bounds = box_around(box_centroid(scene), splat(max_comp(box_extent(scene))));
 }
 
-bool HostSdTree::new_iteration(float directional_threshold, float spatial_threshold, uint32_t iteration, std::string* err) {
-    // subdivide_nodes (stree.rs:55-101): threshold = base * sqrt(2^iteration); freshly appended children are
-    // visited by the same sweep and may split again.
-    const auto t_begin = std::chrono::steady_clock::now();
-    float pow2 = 1.0f;
-    for (uint32_t k = 0; k < iteration; k++) pow2 *= 2.0f;
-    const float threshold = spatial_threshold * sqrtf(pow2);
-    // The sweep itself only decides the topology (it needs nothing but the collector weights): the children of a split
-    // are exact copies of their parent's quadtrees (collector weight halved), so the copies — most of the work — are
-    // left to the parallel pass below; a leaf created here remembers which node still holds the data it descends from.
-    for (size_t i = 0; i < nodes.size(); i++) {
-        if (nodes[i].left != 0 || !(nodes[i].collector.weight > threshold)) continue;
-        const uint32_t l = (uint32_t)nodes.size(), r = l + 1;
-        HostSNode a;
-        a.tree_source = nodes[i].tree_source >= 0 ? nodes[i].tree_source : (int64_t)i;
-        a.axis = (nodes[i].axis + 1) % 3;
-        a.depth = nodes[i].depth + 1;
-        a.sampler.weight = nodes[i].sampler.weight;
-        a.collector.weight = nodes[i].collector.weight / 2.0f;
-        HostSNode b = a;
-        nodes[i].left = l;
-        nodes[i].right = r;
-        nodes.push_back(std::move(a));
-        nodes.push_back(std::move(b));
-    }
+// STree::new_iteration (stree.rs:42-54) and the device image of its result in one go. Per leaf the reference does
+// build -> emit_into(sampler) -> subdivide_and_clear(collector); the sampling copy exists only to be read by the next
+// wave, so it is written straight into the (page-locked) sampling arena instead of into a host-side DTree first.
+bool HostSdTree::refine_and_flatten(SdTreeFlat& out, bool refine, float directional_threshold, float spatial_threshold, uint32_t iteration,
+                                    std::string* err) {
     static const bool trace = getenv("PTGPU_TRACE") != nullptr;
-    const auto t_split = std::chrono::steady_clock::now();
-    // STreeNode::subdivide_dtree for every leaf (stree.rs:49-53,255-260)
-    std::atomic<bool> ok{true};
-    parallel_for(nodes.size(), 16, [&](size_t i) {
-        HostSNode& n = nodes[i];
-        if (n.left != 0) return;
-        if (n.tree_source >= 0) {  // split off this iteration: take the ancestor's quadtrees (it is interior now, nobody writes it)
-            const HostSNode& src = nodes[(size_t)n.tree_source];  // (its sampler is not needed: emit_into below replaces it)
-            n.collector.nodes = src.collector.nodes;
-            n.collector.free_slots = src.collector.free_slots;
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto ms_since = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };
+    if (refine) {
+        // subdivide_nodes (stree.rs:55-101): threshold = base * sqrt(2^iteration); freshly appended children are
+        // visited by the same sweep and may split again. The sweep only decides the topology (it needs nothing but the
+        // collector weights): the children of a split are exact copies of their parent's quadtree (collector weight
+        // halved), so the copies — most of the work — are left to the parallel pass below; a leaf created here
+        // remembers which node still holds the data it descends from.
+        float pow2 = 1.0f;
+        for (uint32_t k = 0; k < iteration; k++) pow2 *= 2.0f;
+        const float threshold = spatial_threshold * sqrtf(pow2);
+        for (size_t i = 0; i < nodes.size(); i++) {
+            if (nodes[i].left != 0 || !(nodes[i].collector.weight > threshold)) continue;
+            const uint32_t l = (uint32_t)nodes.size(), r = l + 1;
+            HostSNode a;
+            a.tree_source = nodes[i].tree_source >= 0 ? nodes[i].tree_source : (int64_t)i;
+            a.axis = (nodes[i].axis + 1) % 3;
+            a.depth = nodes[i].depth + 1;
+            a.sampler_weight = nodes[i].sampler_weight;
+            a.collector.weight = nodes[i].collector.weight / 2.0f;
+            HostSNode b = a;
+            nodes[i].left = l;
+            nodes[i].right = r;
+            nodes.push_back(std::move(a));
+            nodes.push_back(std::move(b));
         }
-        rebuild_sums(n.collector, 0);
-        n.sampler.weight = n.collector.weight;  // emit_into (dtree.rs:325-328)
-        n.sampler.nodes = n.collector.nodes;
-        n.sampler.free_slots = n.collector.free_slots;
-        if (!refine_directional(n.collector, directional_threshold)) ok = false;
-    });
-    // interior nodes that served as copy sources give their quadtrees back
-    parallel_for(nodes.size(), 64, [&](size_t i) {
-        HostSNode& n = nodes[i];
-        n.tree_source = -1;
-        if (n.left != 0 && !n.sampler.nodes.empty()) {
-            n.sampler = HostDTree{};
-            n.collector = HostDTree{};
-        }
-    });
-    if (trace)
-        fprintf(stderr, "[ptgpu]   refine: spatial split %.2f ms (serial), directional %.2f ms (parallel)\n",
-                std::chrono::duration<double, std::milli>(t_split - t_begin).count(),
-                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_split).count());
-    if (!ok) {
-        if (err) *err = "a directional quadtree needs more than 65535 nodes (u16 child links)";
-        return false;
     }
-    return true;
-}
+    const double t_split = ms_since(t_begin);
 
-void HostSdTree::flatten(SdTreeFlat& out) const {
+    // leaf numbering (serial, cheap)
     out.snodes.resize(nodes.size());
-    out.leaf_info.clear();
     out.leaf_snode.clear();
-    // pass 1 (serial, cheap): leaf numbering and arena offsets
-    size_t s_total = 0, c_total = 0;
     for (size_t i = 0; i < nodes.size(); i++) {
         const HostSNode& n = nodes[i];
-        if (n.left != 0) {
-            out.snodes[i] = make_uint4(n.left, n.right, n.axis, 0xffffffffu);
-            continue;
+        if (n.left != 0) out.snodes[i] = make_uint4(n.left, n.right, n.axis, 0xffffffffu);
+        else {
+            out.snodes[i] = make_uint4(0, 0, n.axis, (uint32_t)out.leaf_snode.size());
+            out.leaf_snode.push_back((uint32_t)i);
         }
-        const uint32_t leaf = (uint32_t)out.leaf_info.size();
-        // DTree::mean() == 0 (dtree.rs:71-77) decides between uniform and tree sampling
-        const float mean = n.sampler.weight == 0.0f ? 0.0f : n.sampler.nodes[0].sum() / (kFourPi * n.sampler.weight);
-        // sampler word = sampling-arena offset | mean_is_zero << 31: what Guider::sample needs of the leaf, handed out
-        // by the descent itself (leaf node / jump table) so that no leaf_info load follows it
-        const uint32_t sampler_word = (uint32_t)s_total | (mean == 0.0f ? 0x80000000u : 0u);
-        out.snodes[i] = make_uint4(0, sampler_word, n.axis, leaf);
-        out.leaf_info.push_back(make_uint4((uint32_t)s_total, (uint32_t)c_total, mean == 0.0f ? 1u : 0u, 0u));
-        out.leaf_snode.push_back((uint32_t)i);
-        s_total += n.sampler.nodes.size();
-        c_total += n.collector.nodes.size();
     }
-    // top-of-tree jump table (leaf ids are known now)
+    const size_t n_leaves = out.leaf_snode.size();
+    out.leaf_info.resize(n_leaves);
+
+    // pass A (parallel): DTree::build (sums bottom-up); the sampler takes over the collector's weight (emit_into)
+    parallel_for(n_leaves, 16, [&](size_t leaf) {
+        HostSNode& n = nodes[out.leaf_snode[leaf]];
+        if (refine) {
+            if (n.tree_source >= 0) {  // split off this iteration: take the ancestor's quadtree (it is interior now, nobody writes it)
+                const HostSNode& src = nodes[(size_t)n.tree_source];
+                n.collector.nodes = src.collector.nodes;
+                n.collector.free_slots = src.collector.free_slots;
+            }
+            rebuild_sums(n.collector, 0);
+            n.sampler_weight = n.collector.weight;  // emit_into (dtree.rs:325-328)
+        }
+        // DTree::mean() == 0 (dtree.rs:71-77) decides between uniform and tree sampling
+        const float mean = n.sampler_weight == 0.0f ? 0.0f : n.collector.nodes[0].sum() / (kFourPi * n.sampler_weight);
+        out.leaf_info[leaf] = make_uint4((uint32_t)n.collector.nodes.size(), 0u, mean == 0.0f ? 1u : 0u, 0u);  // .x: size for now
+    });
+    // sampling-arena offsets; the leaf's sampler word = offset | mean_is_zero << 31 is what Guider::sample needs of the
+    // leaf, handed out by the descent itself (leaf node / jump table) so that no leaf_info load follows it
+    size_t s_total = 0;
+    for (size_t leaf = 0; leaf < n_leaves; leaf++) {
+        const uint32_t size = out.leaf_info[leaf].x;
+        out.leaf_info[leaf].x = (uint32_t)s_total;
+        out.snodes[out.leaf_snode[leaf]].y = (uint32_t)s_total | (out.leaf_info[leaf].z ? 0x80000000u : 0u);
+        s_total += size;
+    }
+    sampler_nodes_total = s_total;
+    // top-of-tree jump table
     out.top.resize((size_t)1 << kStreeTopLevels);
     {
         struct Item {
@@ -243,18 +230,49 @@ void HostSdTree::flatten(SdTreeFlat& out) const {
     }
     out.s_rad.resize(s_total);
     out.s_child.resize(s_total);
-    out.c_child.resize(c_total);
-    out.n_collector_nodes = (uint32_t)c_total;
-    // pass 2 (parallel): copy the quadtrees into the arenas
-    parallel_for(out.leaf_snode.size(), 16, [&](size_t leaf) {
-        const HostSNode& n = nodes[out.leaf_snode[leaf]];
-        size_t so = out.leaf_info[leaf].x, co = out.leaf_info[leaf].y;
-        for (const HostDNode& d : n.sampler.nodes) {
+    const double t_a = ms_since(t_begin);
+
+    // pass C (parallel): the sampling copy goes into the arena, then DTree::subdivide_and_clear reshapes the collector
+    std::atomic<bool> ok{true};
+    parallel_for(n_leaves, 16, [&](size_t leaf) {
+        HostSNode& n = nodes[out.leaf_snode[leaf]];
+        size_t so = out.leaf_info[leaf].x;
+        for (const HostDNode& d : n.collector.nodes) {
             out.s_rad[so] = make_float4(d.rad[0], d.rad[1], d.rad[2], d.rad[3]);
             out.s_child[so++] = pack_children(d);
         }
+        if (refine && !refine_directional(n.collector, directional_threshold)) ok = false;
+    });
+    // collector-arena offsets
+    size_t c_total = 0;
+    for (size_t leaf = 0; leaf < n_leaves; leaf++) {
+        out.leaf_info[leaf].y = (uint32_t)c_total;
+        c_total += nodes[out.leaf_snode[leaf]].collector.nodes.size();
+    }
+    out.c_child.resize(c_total);
+    out.n_collector_nodes = (uint32_t)c_total;
+    // pass E (parallel): collector topology
+    parallel_for(n_leaves, 16, [&](size_t leaf) {
+        const HostSNode& n = nodes[out.leaf_snode[leaf]];
+        size_t co = out.leaf_info[leaf].y;
         for (const HostDNode& d : n.collector.nodes) out.c_child[co++] = pack_children(d);
     });
+    if (refine) {
+        // interior nodes that served as copy sources give their quadtrees back
+        parallel_for(nodes.size(), 64, [&](size_t i) {
+            HostSNode& n = nodes[i];
+            n.tree_source = -1;
+            if (n.left != 0 && !n.collector.nodes.empty()) n.collector = HostDTree{};
+        });
+    }
+    if (trace)
+        fprintf(stderr, "[ptgpu]   tree: spatial sweep %.2f ms (serial), sums+offsets %.2f, sampling copy+directional refinement+collector image %.2f\n", t_split,
+                t_a - t_split, ms_since(t_begin) - t_a);
+    if (!ok) {
+        if (err) *err = "a directional quadtree needs more than 65535 nodes (u16 child links)";
+        return false;
+    }
+    return true;
 }
 
 void HostSdTree::load_collector_stats(const SdTreeFlat& layout, const float* stats) {
@@ -268,11 +286,6 @@ void HostSdTree::load_collector_stats(const SdTreeFlat& layout, const float* sta
     });
 }
 
-uint64_t HostSdTree::total_sampler_nodes() const {
-    uint64_t t = 0;
-    for (const HostSNode& n : nodes)
-        if (n.left == 0) t += n.sampler.nodes.size();
-    return t;
-}
+uint64_t HostSdTree::total_sampler_nodes() const { return sampler_nodes_total; }
 
 }  // namespace pt

@@ -59,8 +59,9 @@ struct HostDTree {
         free_slots.clear();
     }
 };
-struct HostSNode {  // STreeNode (stree.rs:12-19)
-    HostDTree sampler, collector;
+struct HostSNode {  // STreeNode (stree.rs:12-19); the sampling DTree lives only in the flattened arena (SdTreeFlat)
+    HostDTree collector;
+    float sampler_weight = 0.0f;  // statistical_weight of the sampling DTree
     uint32_t left = 0, right = 0;  // 0 = leaf
     uint32_t axis = 0, depth = 0;
     int64_t tree_source = -1;  // during new_iteration: node whose quadtrees a freshly split leaf still has to copy
@@ -89,14 +90,15 @@ struct HostSdTree {
     Box3 bounds;
     // STree::new (stree.rs:21-34): cube around the scene bounds' centroid with side = largest extent.
     void init(V3 scene_lo, V3 scene_hi);
-    // STree::new_iteration (stree.rs:42-54): subdivide_nodes, then per leaf build -> emit_into(sampler) -> subdivide_and_clear.
+    // STree::new_iteration (stree.rs:42-54: subdivide_nodes, then per leaf build -> emit_into(sampler) ->
+    // subdivide_and_clear) when `refine` is set, and the flat device image of the resulting tree in any case.
     // Returns false (and sets err) if a DTree would need more than 65535 nodes (u16 links, dtree.rs:18,395).
-    bool new_iteration(float directional_threshold, float spatial_threshold, uint32_t iteration, std::string* err);
-    void flatten(SdTreeFlat& out) const;
+    bool refine_and_flatten(SdTreeFlat& out, bool refine, float directional_threshold, float spatial_threshold, uint32_t iteration, std::string* err);
     // Collector statistics as the device accumulated them: stats = [rad of every collector node (4 floats each) ...,
     // weight of every leaf ...] in the layout flatten() produced.
     void load_collector_stats(const SdTreeFlat& layout, const float* stats);
     uint64_t total_sampler_nodes() const;
+    uint64_t sampler_nodes_total = 0;
 };
 
 }  // namespace pt
