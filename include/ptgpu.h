@@ -141,6 +141,14 @@ int ptgpu_guided_begin(ptgpu_ctx* ctx, const ptgpu_integrator_desc* integrator, 
 int ptgpu_guided_wave(ptgpu_ctx* ctx, uint32_t wave);
 int ptgpu_guided_stats(ptgpu_ctx* ctx, float** device_ptr_out, size_t* count_out);
 int ptgpu_guided_end(ptgpu_ctx* ctx, double* film_rgb_out, double* film_scale_out, ptgpu_stats* stats);
+/* Parity hook for the guided sampler (no reference counterpart as an API). Between two waves: draws n_probes random
+ * points in the SD-tree of the wave just refined and, for each, (a) runs DTree::sample then DTree::pdf as two separate
+ * descents (pt/src/integrator/path_guiding/dtree.rs:98-179) and (b) the single fused descent the shade kernel uses;
+ * also DTree::pdf of a random direction both ways. counts_out = {probes that sampled a non-uniform tree, probes whose
+ * sampled direction / PCG state differ between (a) and (b), probes whose pdf bits differ, pdf-only probes that differ,
+ * probes whose spatial leaf, leaf box or sampler word differ between the jump-table descent and plain node chasing
+ * (STree::leaf, stree.rs:202-229)}: the last four must be 0. */
+int ptgpu_guided_selfcheck(ptgpu_ctx* ctx, uint32_t n_probes, uint64_t seed, uint64_t counts_out[5]);
 
 /* Parity hooks (no reference counterpart as an API; they expose Scene::intersect_t -> Bvh::intersect,
  * pt/src/bvh.rs:86-142, and Scene::occluded, pt/src/scene.rs:229-235, on caller-supplied rays).

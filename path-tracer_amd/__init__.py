@@ -81,7 +81,7 @@ PTGPU_SYMBOLS = [
     "ptgpu_last_error", "ptgpu_init", "ptgpu_destroy", "ptgpu_scene_create", "ptgpu_camera_set", "ptgpu_render",
     "ptgpu_render_shard", "ptgpu_guided_begin", "ptgpu_guided_wave", "ptgpu_guided_stats", "ptgpu_guided_end",
     "ptgpu_trace_batch", "ptgpu_occluded_batch", "ptgpu_scene_info", "ptgpu_scene_bvh", "ptgpu_set_profiling",
-    "ptgpu_set_batch_paths", "ptgpu_kernel_times", "ptgpu_set_census", "ptgpu_census",
+    "ptgpu_set_batch_paths", "ptgpu_kernel_times", "ptgpu_set_census", "ptgpu_census", "ptgpu_guided_selfcheck",
 ]
 PTHOST_SYMBOLS = [
     "pthost_last_error", "pthost_scene_load", "pthost_scene_free", "pthost_scene_desc", "pthost_camera_desc",
@@ -141,6 +141,7 @@ def load_gpu() -> C.CDLL:
         lib.ptgpu_guided_wave.argtypes = [C.c_void_p, C.c_uint32]
         lib.ptgpu_guided_stats.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
         lib.ptgpu_guided_end.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(Stats)]
+        lib.ptgpu_guided_selfcheck.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64, C.POINTER(C.c_uint64)]
         lib.ptgpu_trace_batch.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_uint32, C.c_void_p]
         lib.ptgpu_occluded_batch.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_uint32, C.POINTER(C.c_uint8)]
         lib.ptgpu_scene_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_float)]
@@ -377,6 +378,12 @@ class Context:
         n = C.c_size_t()
         self._check(self.lib.ptgpu_guided_stats(self.handle, C.byref(p), C.byref(n)))
         return p.value, n.value
+
+    def guided_selfcheck(self, n_probes, seed=1):
+        """Fused quadtree walk vs separate sample + pdf descents on the resident tree -> (sampled, sample_diff, pdf_diff, pdf_only_diff, spatial_diff)."""
+        out = (C.c_uint64 * 5)()
+        self._check(self.lib.ptgpu_guided_selfcheck(self.handle, C.c_uint32(n_probes), C.c_uint64(seed), out))
+        return tuple(int(v) for v in out)
 
     def guided_end(self):
         film = np.zeros((self.cam.resy, self.cam.resx, 3), dtype=np.float64)

@@ -795,6 +795,68 @@ __global__ __launch_bounds__(kBlock) void k_guide_scan(SceneDev sc, RenderParams
     }
 }
 
+// STree::leaf by plain node chasing from the root (stree.rs:202-229), as the parity hook's yardstick for stree_leaf.
+PT_D uint32_t stree_leaf_plain(const SdTreeDev& t, V3 p, V3& lo, V3& hi) {
+    lo = t.blo;
+    hi = t.bhi;
+    uint32_t ni = 0;
+    for (int guard = 0; guard < 128; guard++) {
+        const uint4 n = t.snodes[ni];
+        if (n.x == 0) return n.w;
+        const int ax = (int)n.z;
+        const float mid = (get(lo, ax) + get(hi, ax)) / 2.0f;
+        if (get(p, ax) < mid) {
+            set(hi, ax, mid);
+            ni = n.x;
+        } else {
+            set(lo, ax, mid);
+            ni = n.y;
+        }
+    }
+    return t.snodes[ni].w;
+}
+
+// Parity hook (ptgpu_guided_selfcheck): fused walk vs the two separate descents it replaces, on the live tree.
+__global__ __launch_bounds__(kBlock) void k_guided_selfcheck(SdTreeDev tree, uint32_t n_probes, uint64_t seed, unsigned long long* counts) {
+    __shared__ float sm_scales[(kMaxQuadLevel + 1) * kBlock];
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_probes) return;
+    Rng rng = rng_init_pixel(i & 0xffffu, i >> 16, seed);
+    const V3 ext = tree.bhi - tree.blo;
+    const V3 p = tree.blo + mk3(rng_f32(rng), rng_f32(rng), rng_f32(rng)) * ext;
+    V3 lo, hi;
+    uint32_t word = 0;
+    const uint32_t leaf_id = stree_leaf<true>(tree, p, lo, hi, &word);
+    {
+        // jump-table descent vs node chasing: same leaf, same box bits, and the sampler word is the leaf's
+        V3 plo, phi;
+        const uint32_t plain = stree_leaf_plain(tree, p, plo, phi);
+        const uint4 li = tree.leaf_info[plain];
+        const bool same_box = f2u(lo.x) == f2u(plo.x) && f2u(lo.y) == f2u(plo.y) && f2u(lo.z) == f2u(plo.z) && f2u(hi.x) == f2u(phi.x) &&
+                              f2u(hi.y) == f2u(phi.y) && f2u(hi.z) == f2u(phi.z);
+        if (plain != leaf_id || !same_box || (word & 0x7fffffffu) != li.x || (word >> 31) != li.z) atomicAdd(counts + 4, 1ull);
+    }
+    const uint4 leaf = make_uint4(word & 0x7fffffffu, 0u, word >> 31, 0u);
+    float* scales = sm_scales + threadIdx.x;
+    // (a) separate descents
+    Rng ra = rng;
+    const V2 sq_a = dtree_sample(tree, leaf, ra);
+    const float pdf_a = dtree_pdf(tree, leaf, sq_a, scales);
+    // (b) fused
+    Rng rb = rng;
+    V2 sq_b = V2{0.0f, 0.0f};
+    const float pdf_b = dtree_walk(tree, leaf, true, rb, sq_b, scales);
+    if (!leaf.z) atomicAdd(counts + 0, 1ull);
+    if (f2u(sq_a.x) != f2u(sq_b.x) || f2u(sq_a.y) != f2u(sq_b.y) || ra.state != rb.state) atomicAdd(counts + 1, 1ull);
+    if (f2u(pdf_a) != f2u(pdf_b)) atomicAdd(counts + 2, 1ull);
+    // pdf-only lanes
+    V2 sq_c = V2{rng_f32(rng), rng_f32(rng)};
+    const float pdf_c = dtree_pdf(tree, leaf, sq_c, scales);
+    Rng rc = rng;
+    const float pdf_d = dtree_walk(tree, leaf, false, rc, sq_c, scales);
+    if (f2u(pdf_c) != f2u(pdf_d) || rc.state != rng.state) atomicAdd(counts + 3, 1ull);
+}
+
 // c_weight[l] += the private counts of leaf l (whole numbers: the order of the sum does not matter).
 __global__ __launch_bounds__(kBlock) void k_fold_weights(SdTreeDev tree) {
     const uint32_t l = blockIdx.x * blockDim.x + threadIdx.x;

@@ -270,6 +270,26 @@ def test_guided_shards_cover_every_sample_once(gpu_ctx):
     assert total == 48 * 40 * 7
 
 
+def test_guided_fused_walk_equals_separate_sample_and_pdf(gpu_ctx):
+    """The shade kernel serves DTree::sample and DTree::pdf with ONE quadtree descent. On the trees of a real render
+    (after 1, 3 and 5 refinements) the fused walk must return the very direction, PCG state and pdf bits of the two
+    separate descents the reference makes (dtree.rs:98-179)."""
+    sc = pt.LoadedScene("cornell-box-guided", resx=96, resy=96, max_depth=8)
+    gpu_ctx.load(sc)
+    integ = pt.IntegratorDesc.from_buffer_copy(sc.integrator)
+    integ.spatial_threshold = 100.0
+    n_waves = gpu_ctx.guided_begin(integ, 127)
+    assert n_waves == 7
+    for w in range(n_waves):
+        gpu_ctx.guided_wave(w)
+        if w in (1, 3, 5):
+            sampled, d_sample, d_pdf, d_pdf_only, d_spatial = gpu_ctx.guided_selfcheck(200000, seed=w)
+            assert sampled > 100000, sampled          # most probes land in leaves with a trained distribution
+            assert (d_sample, d_pdf, d_pdf_only) == (0, 0, 0)
+            assert d_spatial == 0                     # jump-table spatial descent == plain STree::leaf, box bits included
+    gpu_ctx.guided_end()
+
+
 # ------------------------------------------------------------------ multi-GPU driver rehearsal on one GPU
 @pytest.mark.parametrize("workload", ["guided", "path"])
 def test_bench_rccl_path_rehearsal(workload):
