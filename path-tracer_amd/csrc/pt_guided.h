@@ -462,7 +462,7 @@ struct GuidedParams {
     uint32_t row_stride;   // = capacity
     uint32_t write_film;   // only the last wave reaches the image (film.clear() per wave, mod.rs:80)
     uint32_t shard_index, shard_count;
-    uint32_t tiles_x;
+    uint32_t tiles_x, n_tiles;
 };
 
 PT_HD uint32_t tile_of_pixel(uint32_t pixel, uint32_t resx, uint32_t tiles_x) { return (pixel / resx / 16u) * tiles_x + (pixel % resx) / 16u; }
@@ -475,23 +475,29 @@ PT_HD uint32_t index_in_tile(uint32_t pixel, uint32_t resx) {
     return (x - tx0) + (y % 16u) * tw;
 }
 
-// Per-pass head of PathGuidingIntegrator::render (mod.rs:90-96). Visits every (pass, pixel) pair of the batch and
-// keeps those of this shard: tile t of pass k belongs to shard (t + k) % shard_count, so waves of 1, 2, 4 passes
-// still spread over all GPUs.
+// Per-pass head of PathGuidingIntegrator::render (mod.rs:90-96). Tile t of pass k belongs to shard (t + k) %
+// shard_count, so waves of 1, 2, 4 passes still spread over all GPUs. The launch enumerates only the (pass, tile,
+// pixel-in-tile) triples this shard owns — tiles first_tile(pass) + j * shard_count — so an N-GPU run does 1/N of the
+// work here too; paths come out tile by tile (coherent first bounces).
 __global__ __launch_bounds__(kBlock) void k_raygen_guided(SceneDev sc, CameraDev cam, RenderParams rp, GuidedParams gp, PathCols st, RoundCounters* cnt,
-                                                          uint32_t n_pairs, uint32_t n_pixels, uint64_t first_pass) {
+                                                          uint32_t n_pairs, uint32_t tiles_per_pass, uint64_t first_pass) {
     __shared__ BlockAlloc sm_alloc;
     const uint32_t stride = gridDim.x * blockDim.x;
     const uint32_t n_iter = (n_pairs + stride - 1) / stride;
+    const uint32_t per_pass = tiles_per_pass * 256u;
     for (uint32_t it = 0; it < n_iter; it++) {
         const uint32_t g = it * stride + blockIdx.x * blockDim.x + threadIdx.x;
         bool mine = false;
         uint32_t pixel = 0;
         uint64_t pass = 0;
         if (g < n_pairs) {
-            pixel = g % n_pixels;
-            pass = first_pass + g / n_pixels;
-            mine = (tile_of_pixel(pixel, cam.resx, gp.tiles_x) + pass) % gp.shard_count == gp.shard_index;
+            pass = first_pass + g / per_pass;
+            const uint32_t r = g % per_pass, j = r / 256u, q = r % 256u;
+            const uint32_t first_tile = (gp.shard_index + gp.shard_count - (uint32_t)(pass % gp.shard_count)) % gp.shard_count;
+            const uint32_t tile = first_tile + j * gp.shard_count;
+            const uint32_t x = (tile % gp.tiles_x) * 16u + q % 16u, y = (tile / gp.tiles_x) * 16u + q / 16u;
+            mine = tile < gp.n_tiles && x < cam.resx && y < cam.resy;
+            pixel = y * cam.resx + x;
         }
         uint32_t slot, unused_slot;
         block_alloc2(sm_alloc, &cnt[0], mine, false, slot, unused_slot);
