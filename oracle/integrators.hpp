@@ -477,7 +477,7 @@ inline void guided_render(const Scene& scene, const Camera& cam, const Integrato
         for (auto& n : guider.stree.nodes)
             if (n.is_leaf()) {
                 rep->stree_leaves++;
-                rep->dtree_nodes_total += n.sampler.nodes.size();
+                rep->dtree_nodes_total += n.sampler.nodes.size() - n.sampler.free_slots.size();  // live nodes (freed slots stay in the Vec)
             }
     }
 }

@@ -1,0 +1,186 @@
+// pt_refine.h — the directional half of STree::new_iteration on the device (stree.rs:42-54,255-260; dtree.rs:185-198,
+// 291-328). Between two waves every spatial leaf's collector quadtree is (1) summed bottom-up (DTree::build), (2) copied
+// into the sampling arena the next wave reads (emit_into), (3) reshaped by subdivide_and_clear. The collector sums
+// already live in HBM (the record pass splatted them there, RCCL all-reduced them in place), so doing this here removes
+// the round trip of the whole tree over PCIe and the host pass over it; the host keeps only the spatial binary tree
+// (a few 10^4 nodes), decides its splits from the per-leaf weights, and tells the device which old leaf every new
+// leaf descends from. One thread per leaf: the trees are small (~10^2 nodes) and there are 10^4..10^5 of them.
+// The arithmetic (sum order, IEEE division, 0.25^depth) is the host's/reference's, so the decisions are the same bits;
+// only the numbering of quadtree nodes inside a leaf differs (breadth of the walk here, free-list order there), which
+// nothing observes.
+#pragma once
+#include "pt_guided.h"
+
+namespace pt {
+
+struct RefineArgs {
+    // the generation just trained
+    const uint2* old_child;     // collector topology
+    float4* old_rad;            // collector sums (leaf cells as splatted; interior sums are rebuilt in place)
+    const float* old_weight;    // per old leaf
+    const uint32_t* old_off;    // per old leaf: first node
+    const uint32_t* old_size;   // per old leaf: node count
+    uint32_t n_old_leaves;
+    // the next generation
+    const uint32_t* src_leaf;   // per new leaf: the old leaf it descends from
+    const uint32_t* halvings;   // per new leaf: how many spatial splits lie between (collector weight / 2^k)
+    const uint32_t* s_off;      // per new leaf: first node in the sampling arena (prefix of old sizes, host)
+    uint32_t n_new_leaves;
+    float4* s_rad;              // sampling arena
+    uint2* s_child;
+    uint32_t* new_size;         // per new leaf: node count of the reshaped collector
+    const uint32_t* new_off;    // per new leaf: first node (exclusive scan of new_size)
+    uint2* new_child;           // reshaped collector topology
+    uint4* leaf_info;           // per new leaf: {s_off, new_off, sampler mean == 0, -}
+    uint32_t* error_flag;       // set when a quadtree would need more than 65535 nodes
+    float threshold;            // directional threshold (0.01, mod.rs:73)
+};
+
+PT_D float sum4(float4 r) { return (((0.0f + r.x) + r.y) + r.z) + r.w; }
+
+// DTree::build (dtree.rs:185-198): interior children take the sum of their subtree, bottom-up. One thread per OLD leaf.
+__global__ __launch_bounds__(kBlock) void k_refine_sums(RefineArgs a) {
+    const uint32_t leaf = blockIdx.x * blockDim.x + threadIdx.x;
+    if (leaf >= a.n_old_leaves) return;
+    const uint32_t base = a.old_off[leaf];
+    const uint32_t guard = 6u * a.old_size[leaf] + 8u;
+    // post-order with an explicit stack: entry = node | next child << 16
+    uint32_t stack[kMaxQuadLevel + 40];
+    int sp = 0;
+    stack[sp++] = 0u;
+    for (uint32_t step = 0; sp > 0 && step < guard; step++) {
+        const uint32_t e = stack[sp - 1];
+        const uint32_t node = e & 0xffffu, c = e >> 16;
+        if (c == 4u) {
+            sp--;
+            if (sp > 0) {
+                const uint32_t pe = stack[sp - 1];
+                reinterpret_cast<float*>(a.old_rad + base + (pe & 0xffffu))[(pe >> 16) - 1u] = sum4(a.old_rad[base + node]);
+            }
+            continue;
+        }
+        stack[sp - 1] = node | ((c + 1u) << 16);
+        const uint32_t link = child_link(a.old_child[base + node], (int)c);
+        if (link != 0u && sp < (int)(sizeof(stack) / sizeof(stack[0]))) stack[sp++] = link;
+    }
+}
+
+// DTree::subdivide_and_clear (dtree.rs:291-324) as a pure function of the summed tree: drop subtrees that carry less
+// than `threshold` of the total, split leaf cells that carry more (their four children start with a quarter each and
+// are examined in turn). WRITE = false counts the nodes of the result, WRITE = true emits its topology (sums start at
+// zero: the caller clears the new statistics buffer). Output numbering: a node's interior children get consecutive
+// indices when the node is expanded.
+template <bool WRITE>
+PT_D uint32_t reshape_collector(const RefineArgs& a, uint32_t old_base, uint32_t new_base) {
+    struct Item {
+        uint32_t src_out;  // source node (0xffff = a cell split in this pass) | output index << 16
+        float quarter;     // for a split cell: the value each of its four children starts with
+        uint32_t depth;
+    };
+    Item stack[3 * kMaxQuadLevel + 16];
+    int sp = 0;
+    const float total = sum4(a.old_rad[old_base]);
+    uint32_t counter = 1;
+    stack[sp++] = Item{0u, 0.0f, 1u};
+    for (uint32_t step = 0; sp > 0 && step < 70000u; step++) {
+        const Item it = stack[--sp];
+        const uint32_t src = it.src_out & 0xffffu, out = it.src_out >> 16;
+        float r[4];
+        uint2 links = make_uint2(0u, 0u);
+        if (src != 0xffffu) {
+            const float4 v = a.old_rad[old_base + src];
+            r[0] = v.x; r[1] = v.y; r[2] = v.z; r[3] = v.w;
+            links = a.old_child[old_base + src];
+        } else {
+            r[0] = r[1] = r[2] = r[3] = it.quarter;
+        }
+        uint32_t out_link[4] = {0u, 0u, 0u, 0u};
+        for (int c = 0; c < 4; c++) {
+            float frac;
+            if (total > 0.0f) frac = r[c] / total;
+            else {
+                frac = 1.0f;
+                for (uint32_t k = 0; k < it.depth; k++) frac *= 0.25f;  // 0.25f32.powi(depth), exact
+            }
+            if (frac < a.threshold) continue;  // stays (or becomes) a leaf cell
+            if (counter >= 65535u) {
+                *a.error_flag = 1u;
+                continue;
+            }
+            const uint32_t child_out = counter++;
+            out_link[c] = child_out;
+            const uint32_t link = src != 0xffffu ? child_link(links, c) : 0u;
+            if (sp < (int)(sizeof(stack) / sizeof(stack[0])))
+                stack[sp++] = link == 0u ? Item{0xffffu | (child_out << 16), r[c] / 4.0f, it.depth + 1u} : Item{link | (child_out << 16), 0.0f, it.depth + 1u};
+            else
+                *a.error_flag = 2u;
+        }
+        if (WRITE) a.new_child[new_base + out] = make_uint2(out_link[0] | (out_link[1] << 16), out_link[2] | (out_link[3] << 16));
+    }
+    return counter;
+}
+
+// Per NEW leaf: the sampling copy (emit_into), whether that copy's mean is zero, and the size of the reshaped collector.
+__global__ __launch_bounds__(kBlock) void k_refine_emit_count(RefineArgs a) {
+    const uint32_t leaf = blockIdx.x * blockDim.x + threadIdx.x;
+    if (leaf >= a.n_new_leaves) return;
+    const uint32_t src = a.src_leaf[leaf];
+    const uint32_t ob = a.old_off[src], n = a.old_size[src], sb = a.s_off[leaf];
+    for (uint32_t k = 0; k < n; k++) {
+        a.s_rad[sb + k] = a.old_rad[ob + k];
+        a.s_child[sb + k] = a.old_child[ob + k];
+    }
+    float weight = a.old_weight[src];
+    for (uint32_t k = 0; k < a.halvings[leaf]; k++) weight /= 2.0f;  // STree split: collector weight halves (stree.rs:55-101)
+    // DTree::mean() == 0 (dtree.rs:71-77) decides between uniform and tree sampling
+    const float mean = weight == 0.0f ? 0.0f : sum4(a.old_rad[ob]) / (kFourPi * weight);
+    a.new_size[leaf] = reshape_collector<false>(a, ob, 0u);
+    a.leaf_info[leaf] = make_uint4(sb, 0u, mean == 0.0f ? 1u : 0u, 0u);
+}
+
+__global__ __launch_bounds__(kBlock) void k_refine_write(RefineArgs a) {
+    const uint32_t leaf = blockIdx.x * blockDim.x + threadIdx.x;
+    if (leaf >= a.n_new_leaves) return;
+    const uint32_t nb = a.new_off[leaf];
+    (void)reshape_collector<true>(a, a.old_off[a.src_leaf[leaf]], nb);
+    a.leaf_info[leaf].y = nb;
+}
+
+// Exclusive scan of `n` counts by one workgroup (n is the number of spatial leaves: 1..10^6); out[n] = total.
+__global__ __launch_bounds__(1024) void k_exclusive_scan(const uint32_t* in, uint32_t* out, uint32_t n) {
+    __shared__ uint32_t sm[1024];
+    const uint32_t t = threadIdx.x, per = (n + 1023u) / 1024u;
+    const uint32_t lo = t * per < n ? t * per : n, hi = lo + per < n ? lo + per : n;
+    uint32_t s = 0;
+    for (uint32_t i = lo; i < hi; i++) s += in[i];
+    sm[t] = s;
+    __syncthreads();
+    for (uint32_t off = 1; off < 1024u; off <<= 1) {
+        const uint32_t v = t >= off ? sm[t - off] : 0u;
+        __syncthreads();
+        sm[t] += v;
+        __syncthreads();
+    }
+    uint32_t run = sm[t] - s;
+    for (uint32_t i = lo; i < hi; i++) {
+        out[i] = run;
+        run += in[i];
+    }
+    if (t == 1023u) out[n] = sm[1023];
+}
+
+// The descent hands the leaf's sampler word (sampling-arena offset | mean_is_zero << 31) out of the spatial nodes and
+// the jump table; the host filled in the offsets, the zero-mean bits are known only here.
+__global__ __launch_bounds__(kBlock) void k_refine_patch_words(const uint4* leaf_info, uint4* snodes, uint32_t n_snodes, uint2* top, uint32_t n_top) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_snodes) {
+        const uint4 n = snodes[i];
+        if (n.x == 0u && leaf_info[n.w].z) snodes[i].y = n.y | 0x80000000u;
+    }
+    if (i < n_top) {
+        const uint2 e = top[i];
+        if ((e.x & 0x80000000u) && leaf_info[(e.x >> 5) & 0x3ffffffu].z) top[i].y = e.y | 0x80000000u;
+    }
+}
+
+}  // namespace pt

@@ -102,3 +102,34 @@ struct HostSdTree {
 };
 
 }  // namespace pt
+
+namespace pt {
+
+// ---------------------------------------------------------------------------------------------------------------
+// Host side when the directional quadtrees are refined on the device (pt_refine.h): only the spatial binary tree lives
+// here. Between waves the host learns each leaf's statistical weight and collector size, runs STree::subdivide_nodes
+// (stree.rs:55-101) on the weights, renumbers the leaves and tells the device which old leaf each new leaf copies.
+struct SpatialNode {
+    uint32_t left = 0, right = 0;  // 0 = leaf
+    uint32_t axis = 0;
+    float weight = 0.0f;           // collector statistical_weight (leaves)
+    uint32_t old_leaf = 0;         // leaf id in the generation just trained (leaves)
+    uint32_t halvings = 0;         // spatial splits since then
+    uint32_t leaf_id = 0;          // leaf id in the new generation (leaves)
+};
+struct SpatialFlat {               // what goes up to the device (page-locked)
+    PinnedVec<uint4> snodes;       // {left, right, axis, leaf_id}; leaves: .y = sampling-arena offset (zero-mean bit patched on the device)
+    PinnedVec<uint2> top;          // jump table: {entry, sampling-arena offset}
+    PinnedVec<uint32_t> src_leaf, halvings, s_off;
+    uint64_t sampler_nodes = 0;
+};
+struct HostSpatialTree {
+    std::vector<SpatialNode> nodes;
+    Box3 bounds;
+    uint32_t n_leaves = 1;
+    void init(V3 scene_lo, V3 scene_hi);
+    // weights / sizes: per leaf of the generation just trained (null for the very first image: one untrained leaf of one node)
+    void next_generation(const float* weights, const uint32_t* sizes, bool refine, float spatial_threshold, uint32_t iteration, SpatialFlat& out);
+};
+
+}  // namespace pt
