@@ -4,7 +4,7 @@ configs[3]: 512x512, 512 spp per GPU, max_depth 16, SD-tree statistics all-reduc
 
     python bench.py --gpus N --steps K --warmup W [--workload guided|path|veach-mis|lightpath]
 
-A "step" is one complete render of the workload through the C ABI (all waves, host refinement included). With N > 1
+A "step" is one complete render of the workload through the C ABI (all waves, the SD-tree refinement between them included). With N > 1
 (launched by torch.distributed.run, one rank per GPU) every rank traces its share of each wave's (pass, tile) pairs,
 the collector statistics are summed with an RCCL all-reduce after every wave and the films with one reduce at the
 end. Scaling is WEAK: the sample budget grows with N (spp = 512 * N), per-GPU work stays at 512 spp worth of paths.
