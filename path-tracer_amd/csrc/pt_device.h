@@ -333,8 +333,18 @@ PT_HD bool ray_triangle(V3 ro, const RayShear& rs, V3 p0, V3 p1, V3 p2, float ma
 // top), the box test against the ORIGINAL ray_end_t and the "later triangle wins ties" rule are the
 // reference's, so the reported primitive is the same one bit for bit.
 //
-// Shape of the loop (CDNA4): the reference never culls boxes by the current hit, so which nodes a ray visits does
-// not depend on what it hits. That allows a "while-while" walk — every lane first descends boxes until it stands on
+// Culling. The reference tests every box against the ORIGINAL ray_end_t (bvh.rs:100-106), never against the hit found
+// so far. One cull is provably invisible and is applied here: with kz the ray's dominant axis, every triangle inside a
+// box has all three sheared depths z_i = fl(fl(p_i[kz] - o[kz]) * (1/d[kz])) >= t_dom, the box's entry distance on
+// that axis computed by the very same two operations on a coordinate that bounds p_i[kz] (rounding is monotone). An
+// accepted hit has edge functions of one sign, so t_scaled/det is a convex combination of the z_i up to 7 roundings
+// without cancellation; hence t_dom > 0 and t_dom > best.t * (1 + 32 eps) imply t_scaled beyond max_t * det for every
+// triangle below that node: the reference would reject them all (geom.rs:261-268). Skipping the node changes nothing.
+// (The full slab entry max(t_x, t_y, t_z) would cull a little more, but the other two axes have no such bound in
+// floating point: barycentrics are ill-conditioned at grazing incidence.)
+//
+// Shape of the loop (CDNA4): the order in which nodes are visited does not depend on what the ray hits (only whether a node is skipped
+// does). That allows a "while-while" walk — every lane first descends boxes until it stands on
 // a leaf, then all lanes test their leaf's triangles together — instead of mixing box and triangle work in one
 // divergent loop body. The near child stays in a register; the far-child stack lives in LDS (column `threadIdx.x` of
 // a [depth][256] array, conflict-free, sized from the tree's depth at launch) instead of scratch memory. Up to
@@ -362,6 +372,7 @@ PT_D Hit bvh_intersect(const SceneDev& sc, V3 o, V3 d, float ray_end_t, uint32_t
     const bool nx = inv.x < 0.0f, ny = inv.y < 0.0f, nz = inv.z < 0.0f;
     const uint32_t neg_mask = (nx ? 1u : 0u) | (ny ? 2u : 0u) | (nz ? 4u : 0u);
     const float slack = 1.0f + 2.0f * gamma_n(3.0f);
+    const float kCullSlack = 1.0f + 0x1p-19f;  // 32 eps: see "Culling" above
     const V3 sinv = mk3(slack * inv.x, slack * inv.y, slack * inv.z);  // the reference's `slack * inv * (far - o)` associates this way
     const RayShear shear = ray_shear(d);
     uint32_t* pend = sm_bvh_stack + sc.bvh_stack * kBlock + threadIdx.x;  // leaves waiting for their triangle tests
@@ -374,25 +385,28 @@ PT_D Hit bvh_intersect(const SceneDev& sc, V3 o, V3 d, float ray_end_t, uint32_t
             const float4 n0 = sc.nodes[2 * ni], n1 = sc.nodes[2 * ni + 1];
             const uint32_t offset = f2u(n0.w), meta = f2u(n1.w);
             if (COUNT) (*n_nodes_visited)++;
-            float tmin = 0.0f, tmax = ray_end_t;
+            float tmin = 0.0f, tmax = ray_end_t, t_dom;
             {
                 float near_x = nx ? n1.x : n0.x, far_x = nx ? n0.x : n1.x;
                 float t0 = inv.x * (near_x - o.x);
                 float t1 = sinv.x * (far_x - o.x);
+                t_dom = t0;
                 tmin = fmaxf(tmin, t0);
                 tmax = fminf(tmax, t1);
                 float near_y = ny ? n1.y : n0.y, far_y = ny ? n0.y : n1.y;
                 t0 = inv.y * (near_y - o.y);
                 t1 = sinv.y * (far_y - o.y);
+                t_dom = shear.kz == 1 ? t0 : t_dom;
                 tmin = fmaxf(tmin, t0);
                 tmax = fminf(tmax, t1);
                 float near_z = nz ? n1.z : n0.z, far_z = nz ? n0.z : n1.z;
                 t0 = inv.z * (near_z - o.z);
                 t1 = sinv.z * (far_z - o.z);
+                t_dom = shear.kz == 2 ? t0 : t_dom;
                 tmin = fmaxf(tmin, t0);
                 tmax = fminf(tmax, t1);
             }
-            if ((0.0f <= tmin) && (tmin <= tmax)) {
+            if ((0.0f <= tmin) && (tmin <= tmax) && (t_dom <= best.th.t * kCullSlack)) {
                 const uint32_t ntris = meta & 0xffffu;
                 if (ntris == 0) {
                     const bool neg = ((neg_mask >> (meta >> 16)) & 1u) != 0u;

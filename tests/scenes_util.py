@@ -75,6 +75,44 @@ def grid_scene(n: int = 8):
     return pt.SceneDescription(meshes, [(pt.MAT_LAMBERTIAN, 0.0, GREY, (0, 0, 0, 0))])
 
 
+def near_tie_scene(rng: np.random.Generator, n_sheets: int = 48, n: int = 4):
+    """Stacks of nearly coincident, slightly tilted sheets (separations from 0 to 1e-3, crossing one another): hits of
+    different triangles a few ulps apart in t, the case a traversal that skips boxes by the current hit must get right."""
+    xs = np.linspace(-2.0, 2.0, n + 1)
+    px, py = np.meshgrid(xs, xs, indexing="xy")
+    tris = []
+    for y in range(n):
+        for x in range(n):
+            a = y * (n + 1) + x
+            tris += [(a, a + 1, a + n + 2), (a, a + n + 2, a + n + 1)]
+    tris = np.array(tris, dtype=np.uint32)
+    meshes = []
+    gaps = [0.0, 1.2e-7, 5e-7, 1e-6, 1e-5, 1e-4, 1e-3]
+    z = 0.0
+    for k in range(n_sheets):
+        z += gaps[k % len(gaps)]
+        tilt = rng.uniform(-1, 1, size=2) * gaps[(k * 3 + 1) % len(gaps)]
+        pz = z + tilt[0] * px + tilt[1] * py
+        pts = np.stack([px.ravel(), py.ravel(), pz.ravel()], axis=1).astype(np.float32)
+        mesh = {"points": pts, "triangles": tris, "material_index": 0}
+        if k == 0:
+            mesh["emission"] = GREY
+        meshes.append(mesh)
+    return pt.SceneDescription(meshes, [(pt.MAT_LAMBERTIAN, 0.0, GREY, (0, 0, 0, 0))])
+
+
+def near_tie_rays(rng: np.random.Generator, n: int):
+    """Rays onto near_tie_scene from both sides: normal, oblique and grazing (down to 1e-4 rad), some starting between the sheets."""
+    target = np.stack([rng.uniform(-1.9, 1.9, n), rng.uniform(-1.9, 1.9, n), np.zeros(n)], axis=1)
+    elev = 10.0 ** rng.uniform(-4, 0.19, n)                      # angle to the sheets' plane
+    az = rng.uniform(0, 2 * np.pi, n)
+    side = np.where(rng.uniform(size=n) < 0.5, 1.0, -1.0)
+    d = -np.stack([np.cos(elev) * np.cos(az), np.cos(elev) * np.sin(az), side * np.sin(elev)], axis=1)
+    dist = np.where(rng.uniform(size=n) < 0.1, 10.0 ** rng.uniform(-6, -3, n), rng.uniform(0.5, 6.0, n))
+    o = target - d * dist[:, None]
+    return np.concatenate([o, d, np.full((n, 1), np.inf)], axis=1).astype(np.float32)
+
+
 def random_rays(rng: np.random.Generator, n: int, lo, hi, finite_tmax: bool = False):
     lo = np.asarray(lo, dtype=np.float64)
     hi = np.asarray(hi, dtype=np.float64)

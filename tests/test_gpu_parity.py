@@ -54,6 +54,21 @@ def test_hits_on_coplanar_duplicates_and_shared_edges(gpu_ctx):
     assert_hits_bit_exact(g, c)
 
 
+def test_hits_on_nearly_coincident_sheets(gpu_ctx):
+    """Hits of different triangles a few ulps apart in t, at normal to grazing incidence: the dominant-axis cull of
+    bvh_intersect (pt_device.h) must never change which triangle the reference reports."""
+    rng = np.random.default_rng(11)
+    sc = su.near_tie_scene(rng)
+    o = both(sc, gpu_ctx)
+    rays = su.near_tie_rays(rng, 300000)
+    g, c = gpu_ctx.trace(rays), o.trace(rays)
+    assert c["hit"].mean() > 0.8
+    assert_hits_bit_exact(g, c)
+    idx = np.nonzero(c["hit"])[0][:60000]
+    p = rays[idx, :3] + rays[idx, 3:6] * c["t"][idx, None]
+    assert (gpu_ctx.occluded(p[:-1], p[1:]) == o.occluded(p[:-1], p[1:])).all()
+
+
 def test_empty_batch_and_misses(gpu_ctx):
     sc = su.grid_scene(2)
     both(sc, gpu_ctx)
