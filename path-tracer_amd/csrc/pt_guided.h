@@ -41,12 +41,16 @@ void guided_persist_free(GuidedPersist* p);
 //   child numbering bit0 = x >= mid, bit1 = y >= mid (dtree.rs:331-352).
 // The collector sums c_rad and the per-leaf weights c_weight share ONE float buffer (c_rad first), which is what
 // ptgpu_guided_stats hands to the multi-GPU driver for its all-reduce.
+struct alignas(32) SNode {
+    float4 rad;
+    uint2 child;
+    uint2 pad;
+};
 struct SdTreeDev {
     const uint4* snodes;
     const uint2* top;  // {entry, sampler word of the leaf}: jump table over the first kStreeTopLevels decisions (sdtree_host.h)
     const uint4* leaf_info;
-    const float4* s_rad;
-    const uint2* s_child;
+    const SNode* s_node;  // sampling arena: a node's four child sums and four child links in one 32-byte record (one line per level)
     float4* c_rad;
     const uint2* c_child;
     float* c_weight;
@@ -132,6 +136,50 @@ PT_D uint32_t stree_leaf(const SdTreeDev& t, V3 p, V3& lo, V3& hi, uint32_t* sam
     return t.snodes[ni].w;
 }
 
+// The same descent cut in two for the shade kernel, which wants the table load in flight while it does other work:
+// stree_code = the register halvings (index of the jump-table entry), stree_resolve = what follows the load. Only the
+// leaf's sampler word (sampling-arena offset | mean_is_zero << 31) comes out.
+PT_D uint32_t stree_code(const SdTreeDev& t, V3 p) {
+    V3 lo = t.blo, hi = t.bhi;
+    uint32_t code = 0;
+#pragma unroll
+    for (uint32_t d = 0; d < kStreeTopLevels; d++) {
+        const int ax = (int)(d % 3u);
+        const float mid = (get(lo, ax) + get(hi, ax)) / 2.0f;
+        const bool right = !(get(p, ax) < mid);
+        code = (code << 1) | (right ? 1u : 0u);
+        if (right) set(lo, ax, mid);
+        else set(hi, ax, mid);
+    }
+    return code;
+}
+PT_D uint32_t stree_resolve(const SdTreeDev& t, uint2 entry2, V3 p) {
+    if (entry2.x & 0x80000000u) return entry2.y;
+    // deeper than the table: redo the halvings for the box (rare; cheaper than keeping it in registers), then chase links
+    V3 lo = t.blo, hi = t.bhi;
+    for (uint32_t d = 0; d < kStreeTopLevels; d++) {
+        const int ax = (int)(d % 3u);
+        const float mid = (get(lo, ax) + get(hi, ax)) / 2.0f;
+        if (get(p, ax) < mid) set(hi, ax, mid);
+        else set(lo, ax, mid);
+    }
+    uint32_t ni = entry2.x >> 5;
+    for (int guard = 0; guard < 128; guard++) {
+        const uint4 n = t.snodes[ni];
+        if (n.x == 0) return n.y;
+        const int ax = (int)n.z;
+        const float mid = (get(lo, ax) + get(hi, ax)) / 2.0f;
+        if (get(p, ax) < mid) {
+            set(hi, ax, mid);
+            ni = n.x;
+        } else {
+            set(lo, ax, mid);
+            ni = n.y;
+        }
+    }
+    return t.snodes[ni].y;
+}
+
 // Quadtree cells are dyadic: cell (ix, iy) at `level` spans [ix, ix+1] * 2^-level. The reference halves boxes with
 // (min+max)/2, which is exact for these values, so integer cell coordinates reproduce its boxes bit for bit.
 struct Cell {
@@ -162,10 +210,11 @@ PT_D V2 dtree_sample(const SdTreeDev& t, uint4 leaf, Rng& rng) {
     uint32_t ni = 0;
     Cell cell{0, 0, 0};
     for (;;) {
-        const float4 r = t.s_rad[leaf.x + ni];
+        const float4 r = t.s_node[leaf.x + ni].rad;
+        const uint2 links = t.s_node[leaf.x + ni].child;
         const int c = sample_discrete4(rng_f32(rng), r.x, r.y, r.z, r.w);
         const Cell child{2 * cell.ix + (uint32_t)(c & 1), 2 * cell.iy + (uint32_t)(c >> 1), cell.level + 1};
-        const uint32_t link = child_link(t.s_child[leaf.x + ni], c);
+        const uint32_t link = child_link(links, c);
         if (link == 0 || child.level >= kMaxQuadLevel) {
             const float a = rng_f32(rng), b = rng_f32(rng);
             const Box2 cb = cell_box(child);
@@ -187,7 +236,8 @@ PT_D float dtree_pdf(const SdTreeDev& t, uint4 leaf, V2 p, float* scales) {
     Cell cell{0, 0, 0};
     float result;
     for (;;) {
-        const float4 r = t.s_rad[leaf.x + ni];
+        const float4 r = t.s_node[leaf.x + ni].rad;
+        const uint2 links = t.s_node[leaf.x + ni].child;
         Cell child;
         const int c = cell_child_of(cell, p, child);
         const float rc = comp4(r, c);
@@ -196,7 +246,7 @@ PT_D float dtree_pdf(const SdTreeDev& t, uint4 leaf, V2 p, float* scales) {
             break;
         }
         const float scale = 4.0f * rc / ((((0.0f + r.x) + r.y) + r.z) + r.w);
-        const uint32_t link = child_link(t.s_child[leaf.x + ni], c);
+        const uint32_t link = child_link(links, c);
         if (link == 0 || child.level >= kMaxQuadLevel) {
             result = scale;
             break;
@@ -215,7 +265,8 @@ PT_D float dtree_pdf(const SdTreeDev& t, uint4 leaf, V2 p, float* scales) {
 // factors: the sampling lanes collect them on the way down instead of descending a second time. The rare cases where
 // that argument does not hold (the point was pushed out of its cell by the epsilon/clamp adjustments, or a child of
 // zero weight was drawn) fall back to the separate pdf descent. Returns the tree pdf; `sq` is an output for sampling lanes.
-PT_D float dtree_walk(const SdTreeDev& t, uint4 leaf, bool sample, Rng& rng, V2& sq, float* scales) {
+// `root` is the tree's first node, loaded by the caller ahead of time (one memory round trip off the dependent chain).
+PT_D float dtree_walk(const SdTreeDev& t, uint4 leaf, bool sample, Rng& rng, V2& sq, float* scales, const SNode& root) {
     if (leaf.z) {
         if (sample) {
             const float a = rng_f32(rng), b = rng_f32(rng);
@@ -228,9 +279,9 @@ PT_D float dtree_walk(const SdTreeDev& t, uint4 leaf, bool sample, Rng& rng, V2&
     Cell cell{0, 0, 0};
     float result;
     bool redo = false;
+    float4 r = root.rad;
+    uint2 links = root.child;
     for (;;) {
-        const float4 r = t.s_rad[leaf.x + ni];
-        const uint2 links = t.s_child[leaf.x + ni];
         int c;
         Cell child;
         if (sample) {
@@ -256,6 +307,8 @@ PT_D float dtree_walk(const SdTreeDev& t, uint4 leaf, bool sample, Rng& rng, V2&
         }
         scales[(n++) * kBlock] = scale;
         ni = link;
+        r = t.s_node[leaf.x + ni].rad;
+        links = t.s_node[leaf.x + ni].child;
     }
     if (sample) {
         const float a = rng_f32(rng), b = rng_f32(rng);
@@ -269,15 +322,14 @@ PT_D float dtree_walk(const SdTreeDev& t, uint4 leaf, bool sample, Rng& rng, V2&
     return result * kInvFourPi;
 }
 
-// Guider::sample (path_guiding/mod.rs:315-368).
-PT_D bool guider_sample(const SdTreeDev& t, const Bsdf& bsdf, const Frame& fr, V3 ng, V3 p, V3 wo, Rng& rng, float* lds_scales, BsdfSample& s PT_DBG_PARAMS) {
+// Guider::sample (path_guiding/mod.rs:315-368). `sampler_word` and `root` are the spatial leaf's sampler word and its
+// quadtree's first node, fetched by the caller while it did other work (unused for iteration 0 / specular surfaces).
+PT_D bool guider_sample(const SdTreeDev& t, const Bsdf& bsdf, const Frame& fr, V3 ng, V3 wo, Rng& rng, float* lds_scales, uint32_t sampler_word, const SNode& root,
+                        BsdfSample& s PT_DBG_PARAMS) {
     if (t.iteration == 0 || bsdf_is_specular(bsdf)) {
         const float u1d = rng_f32(rng), ua = rng_f32(rng), ub = rng_f32(rng);
         return bsdf_sample(bsdf, fr, ng, wo, u1d, ua, ub, true, s);
     }
-    V3 lo, hi;
-    uint32_t sampler_word = 0;
-    (void)stree_leaf<false>(t, p, lo, hi, &sampler_word);
     const uint4 leaf = make_uint4(sampler_word & 0x7fffffffu, 0u, sampler_word >> 31, 0u);  // leaf_info's x and z
     PT_TICK(3);
     // Both branches need the tree's pdf at the chosen direction: one quadtree descent per wave serves the lanes
@@ -291,7 +343,7 @@ PT_D bool guider_sample(const SdTreeDev& t, const Bsdf& bsdf, const Frame& fr, V
         PT_TICK(5);
     }
     PT_TICK(4);
-    const float tree_pdf = dtree_walk(t, leaf, use_tree, rng, sq, lds_scales);
+    const float tree_pdf = dtree_walk(t, leaf, use_tree, rng, sq, lds_scales, root);
     PT_TICK(6);
     if (use_tree) {
         s.wi = square_to_dir(sq);
@@ -612,18 +664,41 @@ __global__ __launch_bounds__(kBlock, KINDS != 7 ? PT_GUIDED_DIFFUSE_WAVES : PT_S
                     }
                     Rng rng{(uint64_t)rp4.x | ((uint64_t)rp4.y << 32), rng_inc_for_pixel(rp4.z % rp.resx, rp4.z / rp.resx)};
                     PT_TICK(1);
-                    bool has_nee = false;
+                    // Memory round trips are what this kernel waits for (2-3 waves per SIMD, ~80 % of the time in
+                    // s_waitcnt), so the loads of the two independent chains below — light pick -> its emission row,
+                    // jump table -> first quadtree node — are issued pairwise before either result is used, and
+                    // before the vertex stores (on gfx950 a wave cannot reuse a store's data registers, nor see a
+                    // later load, until the store is acknowledged).
+                    const bool guided_lane = tree.iteration != 0 && !specular;
+                    uint2 top_entry = make_uint2(0u, 0u);
+                    if (guided_lane) top_entry = tree.top[stree_code(tree, p)];
+                    bool has_nee = false, have_light = false;
                     Spec contrib = spec_splat(0.0f);
+                    Tri lt;
+                    float pmf = 0.0f, ua = 0.0f, ub = 0.0f;
                     if (rp.mode != MODE_PT && !specular) {
-                        const float u1d = rng_f32(rng), ua = rng_f32(rng), ub = rng_f32(rng);
-                        Tri lt;
-                        float pmf;
+                        const float u1d = rng_f32(rng);
+                        ua = rng_f32(rng);
+                        ub = rng_f32(rng);
+                        have_light = choose_light(sc, u1d, lt, pmf);
+                    }
+                    Spec le = spec_splat(0.0f);
+                    if (have_light) le = spec_lookup(rp.spec, rp.spec.emission_base + lt.mesh, row);
+                    uint32_t sampler_word = 0x80000000u;
+                    SNode root;
+                    root.rad = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    root.child = make_uint2(0u, 0u);
+                    if (guided_lane) {
+                        sampler_word = stree_resolve(tree, top_entry, p);
+                        root = tree.s_node[sampler_word & 0x7fffffffu];
+                    }
+                    PT_TICK(3);
+                    if (have_light) {
                         LiSample ls;
-                        if (choose_light(sc, u1d, lt, pmf) && light_sample_li(lt, p, ua, ub, ls)) {
+                        if (light_sample_li(lt, p, ua, ub, ls)) {
                             Spec f = bsdf_eval(bsdf, sf.frame, sf.ng, wo, ls.wl, true) / (ls.pdf * pmf);
                             if (!spec_is_black(f)) {
                                 const V3 lp = (ls.blo + ls.bhi) / 2.0f;
-                                const Spec le = spec_lookup(rp.spec, rp.spec.emission_base + lt.mesh, row);
                                 if (rp.mode == MODE_NEE) contrib = f * le;
                                 else {
                                     const float pl = ls.pdf;
@@ -641,7 +716,7 @@ __global__ __launch_bounds__(kBlock, KINDS != 7 ? PT_GUIDED_DIFFUSE_WAVES : PT_S
                     if (!specular && nverts < gp.n_rows) store_vertex_light(gp, nverts, pid, emitted, contrib);
                     PT_TICK(2);
                     BsdfSample bs;
-                    const bool ok = guider_sample(tree, bsdf, sf.frame, sf.ng, p, wo, rng, sm_scales + threadIdx.x, bs PT_DBG_ARGS);
+                    const bool ok = guider_sample(tree, bsdf, sf.frame, sf.ng, wo, rng, sm_scales + threadIdx.x, sampler_word, root, bs PT_DBG_ARGS);
                     rp4.x = (uint32_t)rng.state;
                     rp4.y = (uint32_t)(rng.state >> 32);
                     if (!ok) {
@@ -851,7 +926,7 @@ __global__ __launch_bounds__(kBlock) void k_guided_selfcheck(SdTreeDev tree, uin
     // (b) fused
     Rng rb = rng;
     V2 sq_b = V2{0.0f, 0.0f};
-    const float pdf_b = dtree_walk(tree, leaf, true, rb, sq_b, scales);
+    const float pdf_b = dtree_walk(tree, leaf, true, rb, sq_b, scales, tree.s_node[leaf.x]);
     if (!leaf.z) atomicAdd(counts + 0, 1ull);
     if (f2u(sq_a.x) != f2u(sq_b.x) || f2u(sq_a.y) != f2u(sq_b.y) || ra.state != rb.state) atomicAdd(counts + 1, 1ull);
     if (f2u(pdf_a) != f2u(pdf_b)) atomicAdd(counts + 2, 1ull);
@@ -859,7 +934,7 @@ __global__ __launch_bounds__(kBlock) void k_guided_selfcheck(SdTreeDev tree, uin
     V2 sq_c = V2{rng_f32(rng), rng_f32(rng)};
     const float pdf_c = dtree_pdf(tree, leaf, sq_c, scales);
     Rng rc = rng;
-    const float pdf_d = dtree_walk(tree, leaf, false, rc, sq_c, scales);
+    const float pdf_d = dtree_walk(tree, leaf, false, rc, sq_c, scales, tree.s_node[leaf.x]);
     if (f2u(pdf_c) != f2u(pdf_d) || rc.state != rng.state) atomicAdd(counts + 3, 1ull);
 }
 

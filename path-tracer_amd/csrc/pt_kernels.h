@@ -31,9 +31,13 @@ struct BlockAlloc {
     uint32_t cnt[2];
     uint32_t base[2];
 };
+// Workgroup barrier for data exchanged through LDS only. __syncthreads() also drains the vector-memory counter, i.e.
+// it makes every wave wait for the acknowledgement of the global stores it has just issued (a full memory round trip
+// per loop iteration in the shade kernels); the slot exchange below needs LDS visibility and nothing else.
+PT_D void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 PT_D void block_alloc2(BlockAlloc& sm, RoundCounters* rc, bool want_a, bool want_b, uint32_t& slot_a, uint32_t& slot_b) {
     if (threadIdx.x == 0) sm.cnt[0] = sm.cnt[1] = 0;
-    __syncthreads();
+    lds_barrier();
     const uint32_t lane = __lane_id();
     const unsigned long long ma = __ballot(want_a), mb = __ballot(want_b);
     uint32_t wa = 0, wb = 0;
@@ -43,7 +47,7 @@ PT_D void block_alloc2(BlockAlloc& sm, RoundCounters* rc, bool want_a, bool want
     }
     wa = __shfl(wa, 0);
     wb = __shfl(wb, 0);
-    __syncthreads();
+    lds_barrier();
     if (threadIdx.x == 0) {
         const unsigned long long add = (unsigned long long)sm.cnt[0] | ((unsigned long long)sm.cnt[1] << 32);
         unsigned long long old = 0;
@@ -51,7 +55,7 @@ PT_D void block_alloc2(BlockAlloc& sm, RoundCounters* rc, bool want_a, bool want
         sm.base[0] = (uint32_t)old;
         sm.base[1] = (uint32_t)(old >> 32);
     }
-    __syncthreads();
+    lds_barrier();
     const unsigned long long below = (1ull << lane) - 1ull;
     slot_a = sm.base[0] + wa + (uint32_t)__popcll(ma & below);
     slot_b = sm.base[1] + wb + (uint32_t)__popcll(mb & below);

@@ -26,8 +26,7 @@ struct RefineArgs {
     const uint32_t* halvings;   // per new leaf: how many spatial splits lie between (collector weight / 2^k)
     const uint32_t* s_off;      // per new leaf: first node in the sampling arena (prefix of old sizes, host)
     uint32_t n_new_leaves;
-    float4* s_rad;              // sampling arena
-    uint2* s_child;
+    SNode* s_node;              // sampling arena
     uint32_t* new_size;         // per new leaf: node count of the reshaped collector
     const uint32_t* new_off;    // per new leaf: first node (exclusive scan of new_size)
     uint2* new_child;           // reshaped collector topology
@@ -127,8 +126,7 @@ __global__ __launch_bounds__(kBlock) void k_refine_emit_count(RefineArgs a) {
     const uint32_t src = a.src_leaf[leaf];
     const uint32_t ob = a.old_off[src], n = a.old_size[src], sb = a.s_off[leaf];
     for (uint32_t k = 0; k < n; k++) {
-        a.s_rad[sb + k] = a.old_rad[ob + k];
-        a.s_child[sb + k] = a.old_child[ob + k];
+        a.s_node[sb + k] = SNode{a.old_rad[ob + k], a.old_child[ob + k], make_uint2(0u, 0u)};
     }
     float weight = a.old_weight[src];
     for (uint32_t k = 0; k < a.halvings[leaf]; k++) weight /= 2.0f;  // STree split: collector weight halves (stree.rs:55-101)

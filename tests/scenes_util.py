@@ -38,7 +38,7 @@ def icosphere(level: int):
     return np.array(verts, dtype=np.float32), np.array(f, dtype=np.uint32)
 
 
-def random_soup(rng: np.random.Generator, n_tris: int, n_meshes: int = 3, extent: float = 4.0, size: float = 0.6):
+def random_soup(rng: np.random.Generator, n_tris: int, n_meshes: int = 3, extent: float = 4.0, size: float = 0.6, emissive: bool = True):
     """Random triangle soup split over several meshes (one emissive), with shared vertices inside a mesh so that
     rays through shared edges/vertices exercise the watertight test and its f64 fallback."""
     meshes = []
@@ -53,7 +53,7 @@ def random_soup(rng: np.random.Generator, n_tris: int, n_meshes: int = 3, extent
             tris[i, 0] = tris[i - 1, 1]
             tris[i, 1] = tris[i - 1, 2]
         mesh = {"points": pts, "triangles": tris, "material_index": 0 if m % 2 == 0 else -1}
-        if m == 0:
+        if m == 0 and emissive:
             mesh["emission"] = GREY
         meshes.append(mesh)
     return pt.SceneDescription(meshes, [(pt.MAT_LAMBERTIAN, 0.0, GREY, (0, 0, 0, 0))])

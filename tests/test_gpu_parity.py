@@ -194,6 +194,46 @@ def test_small_batches_equal_one_big_batch(gpu_ctx):
     assert np.allclose(a, b, rtol=1e-9, atol=1e-12)
 
 
+@pytest.mark.parametrize("kind", [pt.INTEGRATOR_PATH, pt.INTEGRATOR_LIGHTPATH])
+def test_ragged_image_sizes_match_oracle(gpu_ctx, kind):
+    """Width and height that are not multiples of the 16 x 16 tile (integrator/mod.rs:34-46 clips the last tiles)."""
+    _compare(gpu_ctx, "cornell-box", kind, (37, 23), 24, max_depth=5)
+
+
+def test_guided_ragged_image_first_wave_and_sample_count(gpu_ctx):
+    """Guided on a 37 x 23 image: wave 0 is the oracle's walk path for path; a 7-spp render (waves 1, 2, 4) traces
+    exactly W * H * 7 samples and the two sides agree on the mean."""
+    sc = pt.LoadedScene("cornell-box-guided", resx=37, resy=23, max_depth=6)
+    o = ob.OracleScene(sc)
+    gpu_ctx.load(sc)
+    gf, gs, gst = gpu_ctx.render(sc.integrator, 1)
+    cf, cs, cst = o.render(sc.camera, sc.integrator, 1)
+    assert gf.shape == cf.shape == (23, 37, 3)
+    rel = np.abs(gf - cf).sum(axis=2) / (np.abs(cf).sum(axis=2) + 1e-6)
+    assert (rel < 1e-3).mean() > 0.99
+    assert gst["extend_rays"] == cst["extend_rays"] and gst["shadow_rays"] == cst["shadow_rays"]
+    gf, gs, gst = gpu_ctx.render(sc.integrator, 7)
+    cf, cs, cst = o.render(sc.camera, sc.integrator, 7)
+    assert gst["samples"] == cst["samples"] == 37 * 23 * 7 and gs == cs == 0.25
+    assert abs((gf * gs).mean() / (cf * cs).mean() - 1.0) < 0.1
+
+
+def test_scene_without_emitters_renders_black(gpu_ctx):
+    """No light to pick (Scene::choose_light returns None, scene.rs:257-268): every integrator returns a black film
+    and traces the rays the oracle traces."""
+    rng = np.random.default_rng(5)
+    sc = su.random_soup(rng, 60, n_meshes=2, emissive=False)
+    o = both(sc, gpu_ctx)
+    cam = pt.make_camera(su.IDENTITY, 60.0, 32, 32)   # inside the soup, looking down +z
+    gpu_ctx.set_camera(cam)
+    for kind in (pt.INTEGRATOR_PATH, pt.INTEGRATOR_GUIDED, pt.INTEGRATOR_LIGHTPATH):
+        integ = pt.make_integrator(kind, 4, pt.MODE_MIS)
+        gf, gs, gst = gpu_ctx.render(integ, 3)
+        cf, cs, cst = o.render(cam, integ, 3)
+        assert not gf.any() and not cf.any()
+        assert gst["extend_rays"] == cst["extend_rays"] and gst["shadow_rays"] == cst["shadow_rays"] == 0, kind
+
+
 def test_error_paths(gpu_ctx):
     with pytest.raises(pt.PtError):
         gpu_ctx.render(pt.make_integrator(7, 4, 0), 1)
