@@ -379,6 +379,17 @@ class Context:
         self._check(self.lib.ptgpu_guided_stats(self.handle, C.byref(p), C.byref(n)))
         return p.value, n.value
 
+    def guided_stats_host(self):
+        """Host copy (float32) of the statistics buffer (diagnostics and tests; the product path keeps it on the device)."""
+        ptr, count = self.guided_stats()
+        out = np.empty(count, dtype=np.float32)
+        hip = C.CDLL("libamdhip64.so")
+        hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        rc = hip.hipMemcpy(out.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), C.c_size_t(count * 4), 2)  # hipMemcpyDeviceToHost
+        if rc != 0:
+            raise PtError(f"hipMemcpy of the statistics buffer failed ({rc})")
+        return out
+
     def guided_selfcheck(self, n_probes, seed=1):
         """Fused quadtree walk vs separate sample + pdf descents on the resident tree -> (sampled, sample_diff, pdf_diff, pdf_only_diff, spatial_diff)."""
         out = (C.c_uint64 * 5)()

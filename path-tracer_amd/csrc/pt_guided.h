@@ -53,6 +53,8 @@ struct SdTreeDev {
     const SNode* s_node;  // sampling arena: a node's four child sums and four child links in one 32-byte record (one line per level)
     float4* c_rad;
     const uint2* c_child;
+    float4* c_lazy;          // per collector node: radiance owed to ALL cells below child c (binned record pass; k_push_lazy)
+    const uint32_t* c_size;  // per leaf: nodes of its collector quadtree (first node: leaf_info[l].y)
     float* c_weight;
     float* w_private;     // kWeightCopies x n_leaves: record counts per leaf, one copy per group of workgroups (folded into
                           // c_weight by k_fold_weights when the wave is done) — every record bumps its leaf's count, and
@@ -965,6 +967,242 @@ __global__ __launch_bounds__(kBlock) void k_guide_splat(SdTreeDev tree, GuidedPa
                 c = rq.q2[base + j];
             }
             stree_record_jittered(tree, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), a.w, b.w, c.x, c.y, active, sm_pend + threadIdx.x);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Binned record pass. The direct splat above pays one memory-side atomic request per touched quadtree node per
+// record (~6 per record, 4 x 10^7 records per batch): that path, not bandwidth, is what bounds it. But a batch brings
+// thousands of records to every spatial leaf, and a leaf's collector quadtree is small (~10^2 nodes): so the records
+// are first grouped by the leaf they land in, and each group is splatted into a copy of that quadtree in LDS (LDS
+// float atomics), which is added to HBM once. Atomic requests to memory drop by two orders of magnitude.
+//   k_guide_locate — per queued record: the two spatial descents of the stochastic filter -> leaf; position within
+//                    the leaf's group from a counter per leaf; the record is rewritten as {dir square, radiance, leaf}.
+//   k_exclusive_scan (pt_refine.h) over the counters -> group starts.
+//   k_guide_scatter — moves each record to its place in the grouped array.
+//   k_guide_splat_bins — workgroups take equal slices of the grouped array; per run of one leaf: quadtree -> LDS,
+//                    box-filter splats with LDS atomics, sums -> HBM (one atomic per touched child sum), weight += run length.
+// Sums are the reference's terms in a different order (as with any atomic accumulation).
+struct RecordBins {
+    uint32_t* count;   // per leaf (zeroed per batch)
+    uint32_t* start;   // n_leaves + 1 (exclusive scan of count)
+    float4* grouped;   // {sq.x, sq.y, radiance, bits(leaf)} in leaf order
+};
+constexpr uint32_t kBinSpillDepth = 3 * kMaxQuadLevel + 4 - kSplatStackLds;  // walk-stack entries beyond the LDS part
+constexpr uint32_t kBinTreeCap = 256;  // quadtree nodes held in LDS (the 1 % subdivision threshold keeps trees near 10^2 nodes); larger trees take the direct path
+
+__global__ __launch_bounds__(kBlock) void k_guide_locate(SdTreeDev tree, GuidedParams gp, RecordQueue rq, RecordBins bins, uint32_t n_paths) {
+    const uint32_t n_chunks = (n_paths + kBlock - 1) / kBlock;
+    const uint32_t lane = __lane_id();
+    for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+        const uint32_t n = rq.count[chunk];
+        const size_t base = (size_t)chunk * kBlock * gp.n_rows;
+        for (uint32_t j0 = 0; j0 < n; j0 += kBlock) {
+            const uint32_t j = j0 + threadIdx.x;
+            const bool active = j < n;
+            uint32_t leaf_id = 0xffffffffu;
+            V2 sq = V2{0.0f, 0.0f};
+            float radiance = 0.0f;
+            if (active) {
+                const float4 a = rq.q0[base + j], b = rq.q1[base + j];
+                const float2 c = rq.q2[base + j];
+                const V3 p = mk3(a.x, a.y, a.z);
+                radiance = a.w;
+                sq = dir_to_square(mk3(b.x, b.y, b.z));
+                V3 lo, hi;
+                (void)stree_leaf<true>(tree, p, lo, hi);
+                const V3 ext = hi - lo;
+                const V3 jlo = p - ext / 2.0f;  // Bounds3::around(p, extent)
+                const V3 jhi = p + ext / 2.0f;
+                const V3 q = clamp3(jlo + mk3(b.w, c.x, c.y) * (jhi - jlo), tree.blo, tree.bhi);
+                leaf_id = stree_leaf<false>(tree, q, lo, hi);
+            }
+            // Position in the leaf's group. Young trees have few leaves (wave 0: one), and same-address atomics
+            // serialise at the memory side: lanes that share the first active lane's leaf take ONE atomic together,
+            // as long as such groups are big; everything else goes lane by lane in a single instruction.
+            uint32_t pos = 0;
+            bool todo = active;
+            for (int rounds = 0; rounds < 8; rounds++) {
+                const unsigned long long live = __ballot(todo);
+                if (live == 0ull) break;
+                const int first = __ffsll((long long)live) - 1;
+                const uint32_t lead = (uint32_t)__shfl((int)leaf_id, first);
+                const bool same = todo && leaf_id == lead;
+                const unsigned long long m = __ballot(same);
+                const uint32_t cnt = (uint32_t)__popcll(m);
+                if (cnt < 8u) break;
+                uint32_t b0 = 0;
+                if ((int)lane == first) b0 = atomicAdd(bins.count + lead, cnt);
+                b0 = (uint32_t)__shfl((int)b0, first);
+                if (same) {
+                    pos = b0 + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                    todo = false;
+                }
+            }
+            if (todo) pos = atomicAdd(bins.count + leaf_id, 1u);
+            if (active) {
+                rq.q0[base + j] = make_float4(sq.x, sq.y, radiance, u2f(leaf_id));
+                rq.q2[base + j] = make_float2(u2f(pos), 0.0f);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_guide_scatter(GuidedParams gp, RecordQueue rq, RecordBins bins, uint32_t n_paths) {
+    const uint32_t n_chunks = (n_paths + kBlock - 1) / kBlock;
+    for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+        const uint32_t n = rq.count[chunk];
+        const size_t base = (size_t)chunk * kBlock * gp.n_rows;
+        for (uint32_t j = threadIdx.x; j < n; j += kBlock) {
+            const float4 r = rq.q0[base + j];
+            const uint32_t pos = f2u(rq.q2[base + j].x);
+            bins.grouped[(size_t)bins.start[f2u(r.w)] + pos] = r;
+        }
+    }
+}
+
+// DTree::record with the box filter for ONE lane against a quadtree whose links and sums are in LDS (LDS_TREE) or in
+// HBM (trees beyond kBinTreeCap: plain global atomics, no batching). Same walk, same terms as dtree_record_box.
+// The walk stack's first kSplatStackLds entries are in LDS; deeper ones (rare) go to `spill`, this thread's column of a
+// preallocated HBM array [kBinSpillDepth][threads] — not to a private array: scratch memory of that size, times the
+// chip's wave slots, exceeds what the runtime keeps allocated, and it would allocate and free it on every dispatch (~1.5 ms).
+template <bool LDS_TREE>
+PT_D void dtree_record_box_lane(const uint2* links_of, float* sums_of, float* lazy_of, V2 p, float radiance, uint32_t* lds_stack, uint2* spill, size_t spill_stride) {
+    int sp = 0;
+    auto push = [&](uint32_t node, Cell cell) {
+        const uint2 w = make_uint2(node | (cell.iy << 16), ((1u << cell.level) | cell.ix) | ((cell.iy >> 16) << 24));
+        if (sp < (int)kSplatStackLds) {
+            lds_stack[(2 * sp) * kBlock] = w.x;
+            lds_stack[(2 * sp + 1) * kBlock] = w.y;
+        } else
+            spill[(size_t)(sp - (int)kSplatStackLds) * spill_stride] = w;
+        sp++;
+    };
+    // DTree::leaf (dtree.rs:81-94): the cell that holds p
+    Cell cell{0, 0, 0};
+    uint32_t ni = 0;
+    for (;;) {
+        Cell child;
+        const int c = cell_child_of(cell, p, child);
+        const uint32_t link = child_link(links_of[ni], c);
+        cell = child;
+        if (link == 0 || child.level >= kMaxQuadLevel) break;
+        ni = link;
+    }
+    const Box2 lb = cell_box(cell);
+    Box2 fp = box2_around(p, box2_extent(lb));
+    fp = Box2{clamp2(V2{0.0f, 0.0f}, fp.lo, fp.hi), clamp2(V2{1.0f, 1.0f}, fp.lo, fp.hi)};  // Bounds2::clamp (bounds.rs:46-50)
+    const float fp_area = box2_area(fp);
+    push(0u, Cell{0, 0, 0});
+    while (sp > 0) {
+        --sp;
+        const uint2 w = sp < (int)kSplatStackLds ? make_uint2(lds_stack[(2 * sp) * kBlock], lds_stack[(2 * sp + 1) * kBlock]) : spill[(size_t)(sp - (int)kSplatStackLds) * spill_stride];
+        const uint32_t sx = w.y & 0xffffffu, level = 31u - (uint32_t)__clz((int)sx);
+        const uint32_t node = w.x & 0xffffu, ix = sx ^ (1u << level), iy = (w.x >> 16) | ((w.y >> 24) << 16);
+        const uint2 links = links_of[node];
+        const float cs = u2f((127u - (level + 1)) << 23);  // child cell size
+        const float x0 = (float)(2 * ix) * cs, xm = (float)(2 * ix + 1) * cs, x1 = (float)(2 * ix + 2) * cs;
+        const float y0 = (float)(2 * iy) * cs, ym = (float)(2 * iy + 1) * cs, y1 = (float)(2 * iy + 2) * cs;
+        const float ex[2] = {fminf(fp.hi.x, xm) - fmaxf(fp.lo.x, x0), fminf(fp.hi.x, x1) - fmaxf(fp.lo.x, xm)};
+        const float ey[2] = {fminf(fp.hi.y, ym) - fmaxf(fp.lo.y, y0), fminf(fp.hi.y, y1) - fmaxf(fp.lo.y, ym)};
+#pragma unroll
+        for (int c = 3; c >= 0; c--) {  // pushed in reverse so that child 0 is expanded first
+            const float ox = ex[c & 1], oy = ey[c >> 1];
+            if (ox <= 0.0f || oy <= 0.0f) continue;  // overlap 0 => weight 0 (or 0/0): skipped by the reference too
+            const float wgt = (ox * oy) / fp_area;
+            if (wgt == 0.0f || !(wgt == wgt)) continue;
+            const uint32_t link = child_link(links, c);
+            if (link == 0 || level + 1 >= kMaxQuadLevel) {
+                if (LDS_TREE) atomicAdd(sums_of + 4 * node + c, radiance * wgt);
+                else unsafeAtomicAdd(sums_of + 4 * node + c, radiance * wgt);
+            } else if (ox == cs && oy == cs) {
+                // The footprint covers this child's cell entirely: every leaf cell below it is owed
+                // radiance * (its area / footprint area) = this term * 4^-(levels below) — a power-of-two scaling,
+                // exact. Owe it to the subtree once (k_push_lazy hands it down) instead of walking the subtree.
+                if (LDS_TREE) atomicAdd(lazy_of + 4 * node + c, radiance * wgt);
+                else unsafeAtomicAdd(lazy_of + 4 * node + c, radiance * wgt);
+            } else if (sp < (int)(kSplatStackLds + kBinSpillDepth))
+                push(link, Cell{2 * ix + (uint32_t)(c & 1), 2 * iy + (uint32_t)(c >> 1), level + 1});
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_guide_splat_bins(SdTreeDev tree, RecordBins bins, uint32_t per_block, uint2* spill_base) {
+    __shared__ uint2 sm_links[kBinTreeCap];
+    __shared__ float sm_sums[4 * kBinTreeCap];
+    __shared__ float sm_lazy[4 * kBinTreeCap];
+    __shared__ uint32_t sm_stack[2 * kSplatStackLds * kBlock];
+    const uint32_t total = bins.start[tree.n_leaves];
+    const size_t spill_stride = (size_t)gridDim.x * kBlock;
+    uint2* spill = spill_base + (size_t)blockIdx.x * kBlock + threadIdx.x;
+    for (uint32_t begin = blockIdx.x * per_block; begin < total; begin += gridDim.x * per_block) {
+        const uint32_t end = min(begin + per_block, total);
+        uint32_t pos = begin;
+        while (pos < end) {  // block-uniform: one run of records of the same leaf per turn
+            const uint32_t leaf_id = f2u(bins.grouped[pos].w);
+            const uint32_t run_end = min(end, bins.start[leaf_id + 1]);
+            const uint32_t c_off = tree.leaf_info[leaf_id].y, n_nodes = tree.c_size[leaf_id];
+            float* sums_hbm = reinterpret_cast<float*>(tree.c_rad + c_off);
+            float* lazy_hbm = reinterpret_cast<float*>(tree.c_lazy + c_off);
+            if (n_nodes <= kBinTreeCap) {
+                for (uint32_t i = threadIdx.x; i < n_nodes; i += kBlock) sm_links[i] = tree.c_child[c_off + i];
+                for (uint32_t i = threadIdx.x; i < 4 * n_nodes; i += kBlock) sm_sums[i] = sm_lazy[i] = 0.0f;
+                __syncthreads();
+                for (uint32_t j = pos + threadIdx.x; j < run_end; j += kBlock) {
+                    const float4 r = bins.grouped[j];
+                    dtree_record_box_lane<true>(sm_links, sm_sums, sm_lazy, V2{r.x, r.y}, r.z, sm_stack + threadIdx.x, spill, spill_stride);
+                }
+                __syncthreads();
+                for (uint32_t k = threadIdx.x; k < 4 * n_nodes; k += kBlock) {
+                    const float v = sm_sums[k], z = sm_lazy[k];
+                    if (v != 0.0f) unsafeAtomicAdd(sums_hbm + k, v);
+                    if (z != 0.0f) unsafeAtomicAdd(lazy_hbm + k, z);
+                }
+                __syncthreads();
+            } else {
+                for (uint32_t j = pos + threadIdx.x; j < run_end; j += kBlock) {
+                    const float4 r = bins.grouped[j];
+                    dtree_record_box_lane<false>(tree.c_child + c_off, sums_hbm, lazy_hbm, V2{r.x, r.y}, r.z, sm_stack + threadIdx.x, spill, spill_stride);
+                }
+            }
+            if (threadIdx.x == 0) unsafeAtomicAdd(tree.c_weight + leaf_id, (float)(run_end - pos));  // DTree::record: weight += 1 per record
+            pos = run_end;
+        }
+    }
+}
+
+// Hands the owed radiance down (see dtree_record_box_lane): one thread per spatial leaf walks its collector quadtree
+// parents first; what a node owes to a child's subtree is split in four, to that child's leaf cells directly and to
+// its interior children as their debt. Runs once per wave, after the last record pass and before the statistics
+// leave the device (ptgpu_guided_stats) or are refined.
+__global__ __launch_bounds__(kBlock) void k_push_lazy(SdTreeDev t) {
+    const uint32_t leaf = blockIdx.x * blockDim.x + threadIdx.x;
+    if (leaf >= t.n_leaves) return;
+    const uint32_t base = t.leaf_info[leaf].y, n = t.c_size[leaf];
+    float* sums = reinterpret_cast<float*>(t.c_rad + base);
+    float* lazy = reinterpret_cast<float*>(t.c_lazy + base);
+    uint32_t stack[3 * kMaxQuadLevel + 8];  // node | level << 16
+    int sp = 0;
+    stack[sp++] = 0u;
+    for (uint32_t step = 0; sp > 0 && step < 4u * n + 8u; step++) {
+        const uint32_t e = stack[--sp];
+        const uint32_t node = e & 0xffffu, level = e >> 16;
+        const uint2 links = t.c_child[base + node];
+        for (int c = 0; c < 4; c++) {
+            const uint32_t link = child_link(links, c);
+            if (link == 0u || level + 1u >= kMaxQuadLevel) continue;  // a leaf cell: the walk added to it directly
+            const float v = lazy[4u * node + (uint32_t)c];
+            if (v != 0.0f) {
+                lazy[4u * node + (uint32_t)c] = 0.0f;
+                const float q = v * 0.25f;
+                const uint2 below = t.c_child[base + link];
+                for (int d = 0; d < 4; d++) {
+                    if (child_link(below, d) == 0u || level + 2u >= kMaxQuadLevel) sums[4u * link + (uint32_t)d] += q;
+                    else lazy[4u * link + (uint32_t)d] += q;
+                }
+            }
+            if (sp < (int)(sizeof(stack) / sizeof(stack[0]))) stack[sp++] = link | ((level + 1u) << 16);
         }
     }
 }

@@ -255,6 +255,39 @@ def test_guided_first_wave_equals_oracle(gpu_ctx):
     assert gst["extend_rays"] == cst["extend_rays"] and gst["shadow_rays"] == cst["shadow_rays"]
 
 
+def test_binned_record_pass_equals_direct_splat(gpu_ctx):
+    """The record pass groups records by spatial leaf, splats them into an LDS copy of the leaf's quadtree and owes
+    fully covered subtrees their share in one term (k_push_lazy hands it down). Same terms as the per-record walk of
+    DTree::record (dtree.rs:235-289) in another order: the collector statistics after a wave must agree with the direct
+    splat's to float-sum accuracy."""
+    import os
+    sc = pt.LoadedScene("cornell-box-guided", resx=96, resy=96, max_depth=8)
+    gpu_ctx.load(sc)
+    stats = {}
+    for mode in ("binned", "direct"):
+        if mode == "direct":
+            os.environ["PTGPU_DIRECT_SPLAT"] = "1"
+        try:
+            n_waves = gpu_ctx.guided_begin(sc.integrator, 7)
+            per_wave = []
+            for w in range(n_waves):
+                gpu_ctx.guided_wave(w)
+                per_wave.append(gpu_ctx.guided_stats_host())
+            gpu_ctx.guided_end()
+        finally:
+            os.environ.pop("PTGPU_DIRECT_SPLAT", None)
+        stats[mode] = per_wave
+    # wave 0 trains the single-node tree, wave 1 the first refined one (dozens of nodes per quadtree, subtrees owed)
+    for w in (0, 1):
+        a, b = stats["binned"][w], stats["direct"][w]
+        assert a.shape == b.shape and a.size > 4
+        assert np.abs(a).sum() > 0
+        assert abs(a.sum() / b.sum() - 1.0) < 1e-4
+        scale = np.abs(b).max()
+        assert np.abs(a - b).max() < 2e-3 * scale, (w, np.abs(a - b).max(), scale)
+    assert stats["binned"][1].size > 100
+
+
 def test_guided_furnace_matches_the_reference_energy_loss(gpu_ctx):
     """See tests/test_oracle_cpu.py: the reference's guided walk loses the vertex whose tree-sampled direction the BSDF
     rejects, so its furnace converges to ~0.81 instead of 1. The GPU must land on the oracle's number, not on 1."""
