@@ -181,4 +181,27 @@ __global__ __launch_bounds__(kBlock) void k_refine_patch_words(const uint4* leaf
     }
 }
 
+// Jump table over the first kStreeTopLevels decisions of the spatial descent (stree_leaf, pt_guided.h): entry `code`
+// (one bit per decision, first decision in the top bit) names where that prefix of decisions ends: a leaf reached
+// after `depth` <= kStreeTopLevels steps — {1 << 31 | leaf << 5 | depth, the leaf's sampler word} — or the interior node
+// standing at depth kStreeTopLevels — {node << 5 | depth, 0}. One thread per entry follows the node links.
+__global__ __launch_bounds__(kBlock) void k_build_top(const uint4* snodes, uint2* top) {
+    const uint32_t code = blockIdx.x * blockDim.x + threadIdx.x;
+    if (code >= (1u << kStreeTopLevels)) return;
+    uint32_t ni = 0, depth = 0;
+    for (;;) {
+        const uint4 n = snodes[ni];
+        if (n.x == 0u) {
+            top[code] = make_uint2(0x80000000u | (n.w << 5) | depth, n.y);
+            return;
+        }
+        if (depth == kStreeTopLevels) {
+            top[code] = make_uint2((ni << 5) | depth, 0u);
+            return;
+        }
+        ni = ((code >> (kStreeTopLevels - 1u - depth)) & 1u) ? n.y : n.x;
+        depth++;
+    }
+}
+
 }  // namespace pt

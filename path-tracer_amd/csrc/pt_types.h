@@ -12,7 +12,10 @@ constexpr int kBlock = 256;     // threads per workgroup of every kernel
 #define PT_LEAF_QUEUE 4
 #endif
 constexpr uint32_t kLeafQueue = PT_LEAF_QUEUE;  // leaves a ray collects before testing their triangles (pt_device.h)
-constexpr uint32_t kStreeTopLevels = 18;  // guided: levels of the spatial tree resolved through the jump table
+#ifndef PT_STREE_TOP_LEVELS
+#define PT_STREE_TOP_LEVELS 18
+#endif
+constexpr uint32_t kStreeTopLevels = PT_STREE_TOP_LEVELS;  // guided: levels of the spatial tree resolved through the jump table
 constexpr int kBvhStack = 64;   // ArrayVec<usize, 64> (pt/src/bvh.rs:94)
 
 enum { MAT_LAMBERTIAN = 0, MAT_DIELECTRIC = 1, MAT_CONDUCTOR = 2 };

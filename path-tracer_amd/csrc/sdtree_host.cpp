@@ -61,27 +61,6 @@ void HostSpatialTree::next_generation(const float* weights, const uint32_t* size
     }
     n_leaves = (uint32_t)out.src_leaf.size();
     out.sampler_nodes = s_total;
-    // top-of-tree jump table (see SdTreeFlat::top)
-    out.top.resize((size_t)1 << kStreeTopLevels);
-    struct Item {
-        uint32_t node, prefix, depth;
-    };
-    std::vector<Item> todo{{0u, 0u, 0u}};
-    while (!todo.empty()) {
-        const Item it = todo.back();
-        todo.pop_back();
-        const SpatialNode& n = nodes[it.node];
-        if (n.left != 0 && it.depth < kStreeTopLevels) {
-            todo.push_back({n.left, it.prefix << 1, it.depth + 1});
-            todo.push_back({n.right, (it.prefix << 1) | 1u, it.depth + 1});
-            continue;
-        }
-        const uint32_t entry = n.left == 0 ? (0x80000000u | (n.leaf_id << 5) | it.depth) : ((it.node << 5) | it.depth);
-        const uint32_t span = 1u << (kStreeTopLevels - it.depth);
-        const uint32_t first = it.prefix << (kStreeTopLevels - it.depth);
-        const uint2 e2 = make_uint2(entry, n.left == 0 ? out.snodes[it.node].y : 0u);
-        for (uint32_t k = 0; k < span; k++) out.top[first + k] = e2;
-    }
 }
 
 }  // namespace pt

@@ -53,7 +53,6 @@ struct SpatialNode {  // STreeNode (stree.rs:12-19) without its DTrees
 };
 struct SpatialFlat {               // what goes up to the device (page-locked)
     PinnedVec<uint4> snodes;       // {left, right, axis, leaf_id}; leaves: .y = sampling-arena offset (zero-mean bit patched on the device)
-    PinnedVec<uint2> top;          // jump table: {entry, sampling-arena offset}
     PinnedVec<uint32_t> src_leaf, halvings, s_off;
     uint64_t sampler_nodes = 0;
 };
