@@ -359,6 +359,19 @@ struct Hit {
 // a triangle is accepted clearly inside the segment, later triangles can only be accepted at t <= best (up to a few
 // ulps), so the answer `best.t != ray_end_t` is already decided and the walk stops. Hits within 0.1 % of the end
 // keep walking so that the reference's exact-equality rule (bvh.rs:137) sees the same final t.
+// Small node arrays are read from LDS. What bounds the walk of a small scene is the vector-memory front end: a
+// 16-byte-per-lane load occupies the CU's address/tag pipeline for >= 16 cycles whatever it hits (k_extend on the
+// Cornell box: TCP_TOTAL_CACHE_ACCESSES ~0.86 per cycle per CU, TA busy 82 %), two per visited node plus three per
+// tested triangle. LDS is a second, independent pipe: nodes from LDS, triangles from L1. Every kernel that walks the
+// BVH calls this first (all threads).
+PT_D void bvh_stage_nodes(const SceneDev& sc) {
+    extern __shared__ uint32_t sm_bvh_stack[];
+    if (sc.lds_nodes) {
+        float4* dst = reinterpret_cast<float4*>(sm_bvh_stack + (sc.bvh_stack + 2 * kLeafQueue) * kBlock);
+        for (uint32_t i = threadIdx.x; i < 2 * sc.n_nodes; i += kBlock) dst[i] = sc.nodes[i];
+        __syncthreads();
+    }
+}
 template <bool COUNT, bool ANY_HIT = false>
 PT_D Hit bvh_intersect(const SceneDev& sc, V3 o, V3 d, float ray_end_t, uint32_t* n_nodes_visited, uint32_t* n_tris_tested) {
     extern __shared__ uint32_t sm_bvh_stack[];
@@ -376,13 +389,22 @@ PT_D Hit bvh_intersect(const SceneDev& sc, V3 o, V3 d, float ray_end_t, uint32_t
     const V3 sinv = mk3(slack * inv.x, slack * inv.y, slack * inv.z);  // the reference's `slack * inv * (far - o)` associates this way
     const RayShear shear = ray_shear(d);
     uint32_t* pend = sm_bvh_stack + sc.bvh_stack * kBlock + threadIdx.x;  // leaves waiting for their triangle tests
+    const float4* lds_nodes = reinterpret_cast<const float4*>(sm_bvh_stack + (sc.bvh_stack + 2 * kLeafQueue) * kBlock);
+    const bool staged = sc.lds_nodes != 0;
     uint32_t sp = 0;
     uint32_t ni = 0;
     bool have_node = true;
     for (;;) {
         uint32_t n_pend = 0;
         while (have_node && n_pend < kLeafQueue) {
-            const float4 n0 = sc.nodes[2 * ni], n1 = sc.nodes[2 * ni + 1];
+            float4 n0, n1;
+            if (staged) {
+                n0 = lds_nodes[2 * ni];
+                n1 = lds_nodes[2 * ni + 1];
+            } else {
+                n0 = sc.nodes[2 * ni];
+                n1 = sc.nodes[2 * ni + 1];
+            }
             const uint32_t offset = f2u(n0.w), meta = f2u(n1.w);
             if (COUNT) (*n_nodes_visited)++;
             float tmin = 0.0f, tmax = ray_end_t, t_dom;
@@ -429,7 +451,12 @@ PT_D Hit bvh_intersect(const SceneDev& sc, V3 o, V3 d, float ray_end_t, uint32_t
         for (uint32_t j = 0; j < n_pend; j++) {
             const uint32_t leaf_first = pend[(2 * j) * kBlock], leaf_n = pend[(2 * j + 1) * kBlock];
             for (uint32_t k = leaf_first; k < leaf_first + leaf_n; k++) {
-                const float4 a = sc.tri_v[3 * k], b = sc.tri_v[3 * k + 1], c = sc.tri_v[3 * k + 2];
+                float4 a = sc.tri_v[3 * k], b = sc.tri_v[3 * k + 1], c = sc.tri_v[3 * k + 2];
+                // Left alone, the compiler re-loads overlapping halves of each vertex (x,y and y,z, for its packed-math
+                // pairings): six vector-memory instructions per triangle instead of three, and vector-memory issue is
+                // what bounds this loop. Passing the loaded values through an empty asm pins one 16-byte load each.
+                // (Closest-hit walks only: the occlusion kernels carry more state and would drop to 7 waves per SIMD.)
+                if (!ANY_HIT) asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(b.x), "+v"(b.y), "+v"(b.z), "+v"(c.x), "+v"(c.y), "+v"(c.z));
                 if (COUNT) (*n_tris_tested)++;
                 TriHit th;
                 if (ray_triangle(o, shear, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), best.th.t, th)) {

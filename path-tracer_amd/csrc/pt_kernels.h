@@ -228,11 +228,13 @@ __global__ __launch_bounds__(kBlock) void k_raygen_camera(SceneDev sc, CameraDev
 // Scene::intersect -> Bvh::intersect (scene.rs:184-186, bvh.rs:86-142) for slots [0, n_active).
 template <bool CENSUS>
 __global__ __launch_bounds__(kBlock, 8) void k_extend(SceneDev sc, PathCols st, HitCols hit, const RoundCounters* cnt, unsigned long long* census) {
+    bvh_stage_nodes(sc);
     const uint32_t n = cnt->n_active;
     const uint32_t stride = gridDim.x * blockDim.x;
     uint32_t cn = 0, ct = 0;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const float4 o = st.o_pdf[i], d = st.d_flags[i];
+        float4 o = st.o_pdf[i], d = st.d_flags[i];
+        asm volatile("" : "+v"(o.x), "+v"(o.y), "+v"(o.z), "+v"(d.x), "+v"(d.y), "+v"(d.z));  // one load each (see bvh_intersect)
         const Hit h = bvh_intersect<CENSUS>(sc, mk3(o.x, o.y, o.z), mk3(d.x, d.y, d.z), f_inf(), &cn, &ct);
         hit.tb[i] = make_float4(h.th.t, h.th.b0, h.th.b1, h.th.b2);
         hit.prim[i] = make_uint2(h.prim, h.tag);
@@ -246,6 +248,7 @@ struct HitOut {
     float t, b0, b1, b2;
 };
 __global__ __launch_bounds__(kBlock) void k_trace_batch(SceneDev sc, const float* rays, uint32_t n, HitOut* out, unsigned long long* counts) {
+    bvh_stage_nodes(sc);
     const uint32_t stride = gridDim.x * blockDim.x;
     unsigned long long nn = 0, nt = 0;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
@@ -273,6 +276,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_batch(SceneDev sc, const float
     }
 }
 __global__ __launch_bounds__(kBlock) void k_occluded_batch(SceneDev sc, const float* from, const float* to, uint32_t n, uint8_t* out) {
+    bvh_stage_nodes(sc);
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const float* a = from + 3 * (size_t)i;
@@ -436,6 +440,7 @@ __global__ __launch_bounds__(kBlock, PT_SHADE_WAVES) void k_shade_path(SceneDev 
 // radiance and finishes paths that ended in shade with this ray still pending.
 template <bool CENSUS>
 __global__ __launch_bounds__(kBlock, 8) void k_occlude_path(SceneDev sc, RenderParams rp, PathCols st, ShadowCols sh, const RoundCounters* cnt, unsigned long long* census) {
+    bvh_stage_nodes(sc);
     const uint32_t n = cnt->n_shadow;
     const uint32_t stride = gridDim.x * blockDim.x;
     uint32_t cn = 0, ct = 0;
@@ -630,6 +635,7 @@ __global__ __launch_bounds__(kBlock, PT_SHADE_WAVES) void k_shade_light(SceneDev
 // Camera-connection visibility + Film::add_splat (camera.rs:161-166) with f64 atomics.
 template <bool CENSUS>
 __global__ __launch_bounds__(kBlock) void k_occlude_splat(SceneDev sc, RenderParams rp, ShadowCols sh, const RoundCounters* cnt, unsigned long long* census) {
+    bvh_stage_nodes(sc);
     const uint32_t n = cnt->n_shadow;
     const uint32_t stride = gridDim.x * blockDim.x;
     const double* r = reinterpret_cast<const double*>(sh.q2);

@@ -11,6 +11,7 @@ constexpr int kBlock = 256;     // threads per workgroup of every kernel
 #ifndef PT_LEAF_QUEUE
 #define PT_LEAF_QUEUE 4
 #endif
+constexpr uint32_t kLdsNodeBudget = 4096;  // bytes: node arrays up to this size are staged in LDS (pt_device.h: bvh_stage_nodes)
 constexpr uint32_t kLeafQueue = PT_LEAF_QUEUE;  // leaves a ray collects before testing their triangles (pt_device.h)
 #ifndef PT_STREE_TOP_LEVELS
 #define PT_STREE_TOP_LEVELS 18
@@ -59,6 +60,7 @@ struct SceneDev {
     const float* d65;                  // CIE_D65_F32[471]
     const double* cie_xyz;             // CIE_XYZ_F64[471][3]
     uint32_t n_nodes, n_tris, n_emissive_tris, n_emissive_meshes;
+    uint32_t lds_nodes;                // != 0: the kernels copy the node array (n_nodes * 32 B, small scenes) into LDS behind the stacks (bvh_stage_nodes)
     uint32_t bvh_stack;                // LDS stack entries per ray = tree depth + 1 (kernels get 256 * bvh_stack * 4 B of dynamic LDS)
     V3 bounds_lo, bounds_hi;
 };

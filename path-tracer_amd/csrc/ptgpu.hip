@@ -442,7 +442,8 @@ int ptgpu_scene_create(ptgpu_ctx* c, const ptgpu_scene_desc* desc) {
     s.n_emissive_tris = (uint32_t)emissive_ids.size();
     s.n_emissive_meshes = n_emissive_meshes;
     s.bvh_stack = bvh_depth + 1;
-    c->bvh_lds = (size_t)kBlock * (s.bvh_stack + 2 * kLeafQueue) * sizeof(uint32_t);
+    s.lds_nodes = (n_nodes * 32 <= kLdsNodeBudget) ? 1u : 0u;
+    c->bvh_lds = (size_t)kBlock * (s.bvh_stack + 2 * kLeafQueue) * sizeof(uint32_t) + (s.lds_nodes ? n_nodes * 32 : 0);
     s.bounds_lo = bvh.nodes[0].bounds.lo;
     s.bounds_hi = bvh.nodes[0].bounds.hi;
     c->have_scene = true;
