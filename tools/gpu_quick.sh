@@ -5,4 +5,4 @@ mkdir -p gpurun_out
 K="${1:-guided or furnace}"
 timeout -k 10 600 python -u -m pytest tests -m gpu -x -q --timeout 300 --timeout-method thread -k "$K" > gpurun_out/t_quick.log 2>&1 || { tail -40 gpurun_out/t_quick.log; exit 1; }
 tail -2 gpurun_out/t_quick.log
-timeout -k 10 300 python -u tools/dbg.py
+timeout -k 10 300 python -u tools/time_workloads.py

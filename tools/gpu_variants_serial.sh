@@ -3,5 +3,5 @@ cd $GRAFT_REPO_ROOT
 export PTGPU_NO_OVERLAP=1
 for L in "$@"; do
   echo "== $L"
-  PTGPU_LIB=$GRAFT_REPO_ROOT/path-tracer_amd/lib/$L timeout -k 10 300 python -u tools/dbg.py 2>&1 | head -1 || exit 1
+  PTGPU_LIB=$GRAFT_REPO_ROOT/path-tracer_amd/lib/$L timeout -k 10 300 python -u tools/time_workloads.py 2>&1 | head -1 || exit 1
 done
