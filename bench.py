@@ -196,7 +196,7 @@ def main() -> int:
     if world == 1 and not args.no_cpu_baseline:
         import oracle_bind as ob
         cores = min(16, os.cpu_count() or 1)
-        cpu_spp = {"guided": 15, "path": 8, "veach-mis": 8, "lightpath": 8, "guided-large": 3, "guided-bidir": 6}[args.workload]
+        cpu_spp = {"guided": 31, "path": 16, "veach-mis": 8, "lightpath": 16, "guided-large": 3, "guided-bidir": 7}[args.workload]
         o = ob.OracleScene(sc)
         t0 = time.perf_counter()
         _, _, cst = o.render(sc.camera, integ, cpu_spp, n_threads=cores)
