@@ -1,0 +1,9 @@
+# Host-side UndefinedBehaviorSanitizer build of libptgpu (device code unchanged): builds path-tracer_amd/lib/v_ubsan.so here;
+# run the GPU suite against it on the box with
+#   PTGPU_LIB=$GRAFT_REPO_ROOT/path-tracer_amd/lib/v_ubsan.so python -m pytest tests -m gpu -q -s 2>&1 | grep "runtime error"
+# (round 1: 46 tests, no reports; the oracle and libpthost were checked the same way with g++ -fsanitize=undefined).
+cd "$(dirname "$0")/.."
+R=$(ls /opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.ubsan_standalone-x86_64.so | head -1)
+/opt/rocm/bin/hipcc -O2 -g -std=c++17 --offload-arch=gfx950 -ffp-contract=off -munsafe-fp-atomics -fPIC -pthread \
+  -Xarch_host -fsanitize=undefined -Xarch_host -fno-sanitize=float-cast-overflow -shared -o path-tracer_amd/lib/v_ubsan.so \
+  path-tracer_amd/csrc/ptgpu.hip path-tracer_amd/csrc/bvh_build.cpp path-tracer_amd/csrc/sdtree_host.cpp -Wl,$R -Wl,-rpath,$(dirname $R)
