@@ -390,6 +390,18 @@ class Context:
             raise PtError(f"hipMemcpy of the statistics buffer failed ({rc})")
         return out
 
+    def guided_stats_set(self, values):
+        """Overwrites the statistics buffer from a host array (tests: what an all-reduce would leave there)."""
+        ptr, count = self.guided_stats()
+        arr = np.ascontiguousarray(values, dtype=np.float32)
+        if arr.size != count:
+            raise PtError(f"statistics buffer holds {count} floats, got {arr.size}")
+        hip = C.CDLL("libamdhip64.so")
+        hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        rc = hip.hipMemcpy(C.c_void_p(ptr), arr.ctypes.data_as(C.c_void_p), C.c_size_t(count * 4), 1)  # hipMemcpyHostToDevice
+        if rc != 0:
+            raise PtError(f"hipMemcpy into the statistics buffer failed ({rc})")
+
     def guided_selfcheck(self, n_probes, seed=1):
         """Fused quadtree walk vs separate sample + pdf descents on the resident tree -> (sampled, sample_diff, pdf_diff, pdf_only_diff, spatial_diff)."""
         out = (C.c_uint64 * 5)()

@@ -358,6 +358,47 @@ def test_guided_shards_cover_every_sample_once(gpu_ctx):
     assert total == 48 * 40 * 7
 
 
+def test_guided_two_shards_with_statistics_exchange(gpu_ctx):
+    """The multi-GPU protocol on one GPU: two contexts render shard 0 and shard 1 of 2, and after every wave but the
+    last their statistics buffers are summed and written back to both (what the in-place RCCL all-reduce leaves).
+    Both ranks must then hold the SAME tree (equal buffer sizes every wave — a collective over unequal buffers would
+    hang an 8-GPU run), every sample must be traced exactly once, and image and tree must agree with the unsharded
+    render up to the statistical differences of another summation order."""
+    sc = pt.LoadedScene("cornell-box-guided", resx=64, resy=64, max_depth=8)
+    spp = 63
+    ranks = [gpu_ctx, pt.Context(0)]
+    try:
+        for c in ranks:
+            c.set_batch_paths(1 << 16)
+            c.load(sc)
+        n_waves = [c.guided_begin(sc.integrator, spp, r, 2) for r, c in enumerate(ranks)]
+        assert n_waves[0] == n_waves[1] == 6
+        sizes = []
+        for w in range(n_waves[0]):
+            for c in ranks:
+                c.guided_wave(w)
+            a, b = ranks[0].guided_stats_host(), ranks[1].guided_stats_host()
+            assert a.shape == b.shape, (w, a.shape, b.shape)
+            sizes.append(a.size)
+            if w + 1 < n_waves[0]:
+                total = a + b
+                for c in ranks:
+                    c.guided_stats_set(total)
+        (fa, sa, sta), (fb, sb, stb) = ranks[0].guided_end(), ranks[1].guided_end()
+    finally:
+        ranks[1].close()
+        gpu_ctx.set_batch_paths(0)
+    assert sa == sb == 1.0 / 32.0
+    assert sta["samples"] + stb["samples"] == 64 * 64 * spp
+    assert sta["stree_nodes"] == stb["stree_nodes"] and sta["dtree_nodes"] == stb["dtree_nodes"]
+    assert sizes[-1] > sizes[0]
+    gpu_ctx.load(sc)
+    fw, sw, stw = gpu_ctx.render(sc.integrator, spp)
+    sharded, whole = (fa + fb) * sa, fw * sw
+    assert abs(sharded.mean() / whole.mean() - 1.0) < 0.05
+    assert abs(sta["stree_nodes"] / stw["stree_nodes"] - 1.0) < 0.1 and abs(sta["dtree_nodes"] / stw["dtree_nodes"] - 1.0) < 0.1
+
+
 def test_guided_fused_walk_equals_separate_sample_and_pdf(gpu_ctx):
     """The shade kernel serves DTree::sample and DTree::pdf with ONE quadtree descent. On the trees of a real render
     (after 1, 3 and 5 refinements) the fused walk must return the very direction, PCG state and pdf bits of the two
