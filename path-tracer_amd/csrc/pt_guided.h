@@ -990,8 +990,12 @@ struct RecordBins {
     uint32_t* start;   // n_leaves + 1 (exclusive scan of count)
     float4* grouped;   // {sq.x, sq.y, radiance, bits(leaf)} in leaf order
 };
-constexpr uint32_t kBinSpillDepth = 3 * kMaxQuadLevel + 4 - kSplatStackLds;  // walk-stack entries beyond the LDS part
-constexpr uint32_t kBinTreeCap = 256;  // quadtree nodes held in LDS (the 1 % subdivision threshold keeps trees near 10^2 nodes); larger trees take the direct path
+// One WAVE per workgroup: a batch brings a leaf ~10^3 records (fewer as the tree grows), and with one wave per leaf run
+// neither do 256 threads share a run of a few hundred records nor do waves wait for one another at barriers.
+constexpr uint32_t kBinBlock = 64;
+constexpr uint32_t kBinStackLds = 4;   // walk-stack entries in LDS (owed subtrees keep the walk on the footprint's rim: shallow)
+constexpr uint32_t kBinSpillDepth = 3 * kMaxQuadLevel + 4 - kBinStackLds;  // walk-stack entries beyond the LDS part
+constexpr uint32_t kBinTreeCap = 192;  // quadtree nodes held in LDS (the 1 % subdivision threshold keeps trees near 10^2 nodes); larger trees take the direct path
 
 __global__ __launch_bounds__(kBlock) void k_guide_locate(SdTreeDev tree, GuidedParams gp, RecordQueue rq, RecordBins bins, uint32_t n_paths) {
     const uint32_t n_chunks = (n_paths + kBlock - 1) / kBlock;
@@ -1065,7 +1069,7 @@ __global__ __launch_bounds__(kBlock) void k_guide_scatter(GuidedParams gp, Recor
 
 // DTree::record with the box filter for ONE lane against a quadtree whose links and sums are in LDS (LDS_TREE) or in
 // HBM (trees beyond kBinTreeCap: plain global atomics, no batching). Same walk, same terms as dtree_record_box.
-// The walk stack's first kSplatStackLds entries are in LDS; deeper ones (rare) go to `spill`, this thread's column of a
+// The walk stack's first kBinStackLds entries are in LDS; deeper ones (rare) go to `spill`, this thread's column of a
 // preallocated HBM array [kBinSpillDepth][threads] — not to a private array: scratch memory of that size, times the
 // chip's wave slots, exceeds what the runtime keeps allocated, and it would allocate and free it on every dispatch (~1.5 ms).
 template <bool LDS_TREE>
@@ -1073,11 +1077,11 @@ PT_D void dtree_record_box_lane(const uint2* links_of, float* sums_of, float* la
     int sp = 0;
     auto push = [&](uint32_t node, Cell cell) {
         const uint2 w = make_uint2(node | (cell.iy << 16), ((1u << cell.level) | cell.ix) | ((cell.iy >> 16) << 24));
-        if (sp < (int)kSplatStackLds) {
-            lds_stack[(2 * sp) * kBlock] = w.x;
-            lds_stack[(2 * sp + 1) * kBlock] = w.y;
+        if (sp < (int)kBinStackLds) {
+            lds_stack[(2 * sp) * kBinBlock] = w.x;
+            lds_stack[(2 * sp + 1) * kBinBlock] = w.y;
         } else
-            spill[(size_t)(sp - (int)kSplatStackLds) * spill_stride] = w;
+            spill[(size_t)(sp - (int)kBinStackLds) * spill_stride] = w;
         sp++;
     };
     // DTree::leaf (dtree.rs:81-94): the cell that holds p
@@ -1098,7 +1102,7 @@ PT_D void dtree_record_box_lane(const uint2* links_of, float* sums_of, float* la
     push(0u, Cell{0, 0, 0});
     while (sp > 0) {
         --sp;
-        const uint2 w = sp < (int)kSplatStackLds ? make_uint2(lds_stack[(2 * sp) * kBlock], lds_stack[(2 * sp + 1) * kBlock]) : spill[(size_t)(sp - (int)kSplatStackLds) * spill_stride];
+        const uint2 w = sp < (int)kBinStackLds ? make_uint2(lds_stack[(2 * sp) * kBinBlock], lds_stack[(2 * sp + 1) * kBinBlock]) : spill[(size_t)(sp - (int)kBinStackLds) * spill_stride];
         const uint32_t sx = w.y & 0xffffffu, level = 31u - (uint32_t)__clz((int)sx);
         const uint32_t node = w.x & 0xffffu, ix = sx ^ (1u << level), iy = (w.x >> 16) | ((w.y >> 24) << 16);
         const uint2 links = links_of[node];
@@ -1123,20 +1127,20 @@ PT_D void dtree_record_box_lane(const uint2* links_of, float* sums_of, float* la
                 // exact. Owe it to the subtree once (k_push_lazy hands it down) instead of walking the subtree.
                 if (LDS_TREE) atomicAdd(lazy_of + 4 * node + c, radiance * wgt);
                 else unsafeAtomicAdd(lazy_of + 4 * node + c, radiance * wgt);
-            } else if (sp < (int)(kSplatStackLds + kBinSpillDepth))
+            } else if (sp < (int)(kBinStackLds + kBinSpillDepth))
                 push(link, Cell{2 * ix + (uint32_t)(c & 1), 2 * iy + (uint32_t)(c >> 1), level + 1});
         }
     }
 }
 
-__global__ __launch_bounds__(kBlock) void k_guide_splat_bins(SdTreeDev tree, RecordBins bins, uint32_t per_block, uint2* spill_base) {
+__global__ __launch_bounds__(kBinBlock) void k_guide_splat_bins(SdTreeDev tree, RecordBins bins, uint32_t per_block, uint2* spill_base) {
     __shared__ uint2 sm_links[kBinTreeCap];
     __shared__ float sm_sums[4 * kBinTreeCap];
     __shared__ float sm_lazy[4 * kBinTreeCap];
-    __shared__ uint32_t sm_stack[2 * kSplatStackLds * kBlock];
+    __shared__ uint32_t sm_stack[2 * kBinStackLds * kBinBlock];
     const uint32_t total = bins.start[tree.n_leaves];
-    const size_t spill_stride = (size_t)gridDim.x * kBlock;
-    uint2* spill = spill_base + (size_t)blockIdx.x * kBlock + threadIdx.x;
+    const size_t spill_stride = (size_t)gridDim.x * kBinBlock;
+    uint2* spill = spill_base + (size_t)blockIdx.x * kBinBlock + threadIdx.x;
     for (uint32_t begin = blockIdx.x * per_block; begin < total; begin += gridDim.x * per_block) {
         const uint32_t end = min(begin + per_block, total);
         uint32_t pos = begin;
@@ -1147,22 +1151,22 @@ __global__ __launch_bounds__(kBlock) void k_guide_splat_bins(SdTreeDev tree, Rec
             float* sums_hbm = reinterpret_cast<float*>(tree.c_rad + c_off);
             float* lazy_hbm = reinterpret_cast<float*>(tree.c_lazy + c_off);
             if (n_nodes <= kBinTreeCap) {
-                for (uint32_t i = threadIdx.x; i < n_nodes; i += kBlock) sm_links[i] = tree.c_child[c_off + i];
-                for (uint32_t i = threadIdx.x; i < 4 * n_nodes; i += kBlock) sm_sums[i] = sm_lazy[i] = 0.0f;
+                for (uint32_t i = threadIdx.x; i < n_nodes; i += kBinBlock) sm_links[i] = tree.c_child[c_off + i];
+                for (uint32_t i = threadIdx.x; i < 4 * n_nodes; i += kBinBlock) sm_sums[i] = sm_lazy[i] = 0.0f;
                 __syncthreads();
-                for (uint32_t j = pos + threadIdx.x; j < run_end; j += kBlock) {
+                for (uint32_t j = pos + threadIdx.x; j < run_end; j += kBinBlock) {
                     const float4 r = bins.grouped[j];
                     dtree_record_box_lane<true>(sm_links, sm_sums, sm_lazy, V2{r.x, r.y}, r.z, sm_stack + threadIdx.x, spill, spill_stride);
                 }
                 __syncthreads();
-                for (uint32_t k = threadIdx.x; k < 4 * n_nodes; k += kBlock) {
+                for (uint32_t k = threadIdx.x; k < 4 * n_nodes; k += kBinBlock) {
                     const float v = sm_sums[k], z = sm_lazy[k];
                     if (v != 0.0f) unsafeAtomicAdd(sums_hbm + k, v);
                     if (z != 0.0f) unsafeAtomicAdd(lazy_hbm + k, z);
                 }
                 __syncthreads();
             } else {
-                for (uint32_t j = pos + threadIdx.x; j < run_end; j += kBlock) {
+                for (uint32_t j = pos + threadIdx.x; j < run_end; j += kBinBlock) {
                     const float4 r = bins.grouped[j];
                     dtree_record_box_lane<false>(tree.c_child + c_off, sums_hbm, lazy_hbm, V2{r.x, r.y}, r.z, sm_stack + threadIdx.x, spill, spill_stride);
                 }
