@@ -14,7 +14,7 @@ constexpr int kBlock = 256;     // threads per workgroup of every kernel
 constexpr uint32_t kLdsNodeBudget = 4096;  // bytes: node arrays up to this size are staged in LDS (pt_device.h: bvh_stage_nodes)
 constexpr uint32_t kLeafQueue = PT_LEAF_QUEUE;  // leaves a ray collects before testing their triangles (pt_device.h)
 #ifndef PT_STREE_TOP_LEVELS
-#define PT_STREE_TOP_LEVELS 18
+#define PT_STREE_TOP_LEVELS 21
 #endif
 constexpr uint32_t kStreeTopLevels = PT_STREE_TOP_LEVELS;  // guided: levels of the spatial tree resolved through the jump table
 constexpr int kBvhStack = 64;   // ArrayVec<usize, 64> (pt/src/bvh.rs:94)

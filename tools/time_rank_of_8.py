@@ -10,7 +10,7 @@ ctx.render(sc.integrator, 64)
 t = time.time(); f, s, st = ctx.render(sc.integrator, 512); one = time.time() - t
 print(f"N=1: 512 spp in {one:.3f} s", flush=True)
 ctx.set_profiling(True)
-for world in (1, 8, 8):
+for world in (1, 8, 8, 1, 8):
     n = ctx.guided_begin(sc.integrator, 512 * world, 0, world)
     wave_s = 0.0; per = []
     for w in range(n):
