@@ -1185,29 +1185,26 @@ __global__ __launch_bounds__(kBlock) void k_push_lazy(SdTreeDev t) {
     const uint32_t leaf = blockIdx.x * blockDim.x + threadIdx.x;
     if (leaf >= t.n_leaves) return;
     const uint32_t base = t.leaf_info[leaf].y, n = t.c_size[leaf];
-    float* sums = reinterpret_cast<float*>(t.c_rad + base);
-    float* lazy = reinterpret_cast<float*>(t.c_lazy + base);
-    uint32_t stack[3 * kMaxQuadLevel + 8];  // node | level << 16
-    int sp = 0;
-    stack[sp++] = 0u;
-    for (uint32_t step = 0; sp > 0 && step < 4u * n + 8u; step++) {
-        const uint32_t e = stack[--sp];
-        const uint32_t node = e & 0xffffu, level = e >> 16;
-        const uint2 links = t.c_child[base + node];
+    // interior children have larger indices than their parent and lie above kMaxQuadLevel (pt_refine.h:
+    // reshape_collector), so one sweep from the first node to the last sees every debt after it has been handed down
+    for (uint32_t i = 0; i < n; i++) {
+        const float4 z = t.c_lazy[base + i];
+        if (z.x == 0.0f && z.y == 0.0f && z.z == 0.0f && z.w == 0.0f) continue;
+        const uint2 links = t.c_child[base + i];
+        t.c_lazy[base + i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        const float owed[4] = {z.x, z.y, z.z, z.w};
         for (int c = 0; c < 4; c++) {
             const uint32_t link = child_link(links, c);
-            if (link == 0u || level + 1u >= kMaxQuadLevel) continue;  // a leaf cell: the walk added to it directly
-            const float v = lazy[4u * node + (uint32_t)c];
-            if (v != 0.0f) {
-                lazy[4u * node + (uint32_t)c] = 0.0f;
-                const float q = v * 0.25f;
-                const uint2 below = t.c_child[base + link];
-                for (int d = 0; d < 4; d++) {
-                    if (child_link(below, d) == 0u || level + 2u >= kMaxQuadLevel) sums[4u * link + (uint32_t)d] += q;
-                    else lazy[4u * link + (uint32_t)d] += q;
-                }
-            }
-            if (sp < (int)(sizeof(stack) / sizeof(stack[0]))) stack[sp++] = link | ((level + 1u) << 16);
+            if (owed[c] == 0.0f || link <= i || link >= n) continue;
+            const float q = owed[c] * 0.25f;
+            const uint2 below = t.c_child[base + link];
+            float4 s = t.c_rad[base + link], d = t.c_lazy[base + link];
+            if (child_link(below, 0) == 0u) s.x += q; else d.x += q;
+            if (child_link(below, 1) == 0u) s.y += q; else d.y += q;
+            if (child_link(below, 2) == 0u) s.z += q; else d.z += q;
+            if (child_link(below, 3) == 0u) s.w += q; else d.w += q;
+            t.c_rad[base + link] = s;
+            t.c_lazy[base + link] = d;
         }
     }
 }

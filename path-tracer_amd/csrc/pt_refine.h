@@ -38,29 +38,22 @@ struct RefineArgs {
 PT_D float sum4(float4 r) { return (((0.0f + r.x) + r.y) + r.z) + r.w; }
 
 // DTree::build (dtree.rs:185-198): interior children take the sum of their subtree, bottom-up. One thread per OLD leaf.
+// Every node's interior children have larger indices than the node (reshape_collector numbers a child when its parent
+// is expanded), so one sweep from the last node to the first finds every child's sums already final — no stack.
 __global__ __launch_bounds__(kBlock) void k_refine_sums(RefineArgs a) {
     const uint32_t leaf = blockIdx.x * blockDim.x + threadIdx.x;
     if (leaf >= a.n_old_leaves) return;
-    const uint32_t base = a.old_off[leaf];
-    const uint32_t guard = 6u * a.old_size[leaf] + 8u;
-    // post-order with an explicit stack: entry = node | next child << 16
-    uint32_t stack[kMaxQuadLevel + 40];
-    int sp = 0;
-    stack[sp++] = 0u;
-    for (uint32_t step = 0; sp > 0 && step < guard; step++) {
-        const uint32_t e = stack[sp - 1];
-        const uint32_t node = e & 0xffffu, c = e >> 16;
-        if (c == 4u) {
-            sp--;
-            if (sp > 0) {
-                const uint32_t pe = stack[sp - 1];
-                reinterpret_cast<float*>(a.old_rad + base + (pe & 0xffffu))[(pe >> 16) - 1u] = sum4(a.old_rad[base + node]);
-            }
-            continue;
-        }
-        stack[sp - 1] = node | ((c + 1u) << 16);
-        const uint32_t link = child_link(a.old_child[base + node], (int)c);
-        if (link != 0u && sp < (int)(sizeof(stack) / sizeof(stack[0]))) stack[sp++] = link;
+    const uint32_t base = a.old_off[leaf], n = a.old_size[leaf];
+    for (uint32_t i = n; i-- > 0;) {
+        const uint2 links = a.old_child[base + i];
+        if ((links.x | links.y) == 0u) continue;  // four leaf cells
+        float4 r = a.old_rad[base + i];
+        const uint32_t l0 = child_link(links, 0), l1 = child_link(links, 1), l2 = child_link(links, 2), l3 = child_link(links, 3);
+        if (l0 > i && l0 < n) r.x = sum4(a.old_rad[base + l0]);
+        if (l1 > i && l1 < n) r.y = sum4(a.old_rad[base + l1]);
+        if (l2 > i && l2 < n) r.z = sum4(a.old_rad[base + l2]);
+        if (l3 > i && l3 < n) r.w = sum4(a.old_rad[base + l3]);
+        a.old_rad[base + i] = r;
     }
 }
 
@@ -102,6 +95,7 @@ PT_D uint32_t reshape_collector(const RefineArgs& a, uint32_t old_base, uint32_t
                 for (uint32_t k = 0; k < it.depth; k++) frac *= 0.25f;  // 0.25f32.powi(depth), exact
             }
             if (frac < a.threshold) continue;  // stays (or becomes) a leaf cell
+            if (it.depth >= kMaxQuadLevel) continue;  // a node there would be out of every walk's reach (they stop at kMaxQuadLevel)
             if (counter >= 65535u) {
                 *a.error_flag = 1u;
                 continue;
