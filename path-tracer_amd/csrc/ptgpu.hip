@@ -672,16 +672,14 @@ int run_batch_path_like(ptgpu_ctx* c, bool light, const RenderParams& rp, uint32
         std::swap(A, B);
         round++;
         if (round >= sure_rounds || (round & 15) == 0) {  // the host looks at the queue length rarely: every look drains the stream
-            RoundCounters rc;
-            HIP_TRY(hipMemcpyAsync(&rc, cnt + round, sizeof(rc), hipMemcpyDeviceToHost, c->stream));
+            // all counters so far in one copy: the look that finds the queue empty is also the batch's statistics
+            HIP_TRY(hipMemcpyAsync(c->h_counters.data(), cnt, (size_t)(round + 1) * sizeof(RoundCounters), hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(hipStreamSynchronize(c->stream));
-            if (getenv("PTGPU_DEBUG") && round > (int)rp.max_depth + 2 && round < 200) fprintf(stderr, "[ptgpu] round %d: %u paths alive\n", round, rc.n_active);
-            if (rc.n_active == 0) break;
+            if (getenv("PTGPU_DEBUG") && round > (int)rp.max_depth + 2 && round < 200) fprintf(stderr, "[ptgpu] round %d: %u paths alive\n", round, c->h_counters[round].n_active);
+            if (c->h_counters[round].n_active == 0) break;
         }
     }
     if (stats) {
-        HIP_TRY(hipMemcpyAsync(c->h_counters.data(), cnt, (size_t)(round + 1) * sizeof(RoundCounters), hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
         for (int r = 0; r <= round; r++) {
             stats->extend_rays += c->h_counters[r].n_active;
             stats->shadow_rays += c->h_counters[r].n_shadow;
