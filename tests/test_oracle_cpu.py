@@ -316,6 +316,47 @@ def test_loader_errors_are_reported_not_fatal():
         pt.LoadedScene("no-such-scene")
 
 
+def test_loader_reads_ply_and_obj_files(tmp_path):
+    """`<shape type="ply">` (ascii and binary little-endian, with and without normals; parser/mod.rs:1173-1256) and
+    `<shape type="obj">` from files next to the scene, with the shape's to_world applied."""
+    import struct
+    scene = tmp_path / "filemesh"
+    scene.mkdir()
+    verts = [(0, 0, 0), (1, 0, 0), (1, 1, 0), (0, 1, 0)]
+    faces = [(0, 1, 2), (0, 2, 3)]
+    (scene / "quad_ascii.ply").write_text(
+        "ply\nformat ascii 1.0\nelement vertex 4\nproperty float x\nproperty float y\nproperty float z\n"
+        "element face 2\nproperty list uchar int vertex_indices\nend_header\n"
+        + "".join(f"{x} {y} {z}\n" for x, y, z in verts) + "".join(f"3 {a} {b} {c}\n" for a, b, c in faces))
+    header = ("ply\nformat binary_little_endian 1.0\nelement vertex 4\nproperty float x\nproperty float y\nproperty float z\n"
+              "property float nx\nproperty float ny\nproperty float nz\nelement face 2\nproperty list uchar uint vertex_indices\nend_header\n").encode()
+    body = b"".join(struct.pack("<6f", x, y, z, 0.0, 0.0, 1.0) for x, y, z in verts) + b"".join(struct.pack("<B3I", 3, a, b, c) for a, b, c in faces)
+    (scene / "quad_bin.ply").write_bytes(header + body)
+    (scene / "quad.obj").write_text("".join(f"v {x} {y} {z}\n" for x, y, z in verts) + "vn 0 0 1\n" * 4 + "f 1//1 2//2 3//3\nf 1//1 3//3 4//4\n")  # one normal per position (parser/mod.rs:1297)
+    shape = lambda kind, fn, dx: (f'<shape type="{kind}"><string name="filename" value="{fn}"/><transform name="to_world"><scale value="2"/>'
+                                  f'<translate value="{dx}, 0, 0"/></transform><ref id="M"/></shape>')
+    (scene / "scene_v3.xml").write_text(
+        '<scene version="3.0.0" output="filemesh.png"><integrator type="path"><integer name="max_depth" value="4"/></integrator>'
+        '<sensor type="perspective"><float name="fov" value="40"/><transform name="to_world"><matrix value="1 0 0 0 0 1 0 0 0 0 1 -5 0 0 0 1"/></transform>'
+        '<sampler type="independent"><integer name="sample_count" value="4"/></sampler>'
+        '<film type="hdrfilm"><integer name="width" value="32"/><integer name="height" value="32"/></film></sensor>'
+        '<bsdf type="diffuse" id="M"><rgb name="reflectance" value="0.5, 0.5, 0.5"/></bsdf>'
+        + shape("ply", "quad_ascii.ply", 0) + shape("ply", "quad_bin.ply", 10) + shape("obj", "quad.obj", 20) + "</scene>")
+    sc = pt.LoadedScene("filemesh", collection=tmp_path)
+    d = sc.pointer().contents
+    assert d.n_meshes == 3
+    los = []
+    for m in range(3):
+        mesh = d.meshes[m]
+        assert mesh.n_triangles == 2 and mesh.n_points >= 4
+        P = np.ctypeslib.as_array(mesh.points, shape=(mesh.n_points, 3))
+        assert np.allclose(P.max(axis=0) - P.min(axis=0), [2, 2, 0])   # the unit quad, scaled by 2
+        los.append(P[:, 0].min())
+    assert sorted(np.round(los).tolist()) == [0.0, 10.0, 20.0]             # each shape's own translation
+    has_normals = [bool(d.meshes[m].normals) for m in range(3)]
+    assert has_normals.count(True) >= 1 and has_normals.count(False) >= 1   # the ascii file carries none
+
+
 def test_glass_cube_transform_order():
     """scale 0.5 -> rotate y 45 deg -> translate (0,1,0), each pre-multiplied (parser/mod.rs:666-695)."""
     sc = pt.LoadedScene("cornell-box")
