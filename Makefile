@@ -16,7 +16,7 @@ $(LIB)/libptgpu.so: $(CSRC)/ptgpu.hip $(CSRC)/bvh_build.cpp $(CSRC)/sdtree_host.
 
 $(LIB)/libpthost.so: $(PKG)/host/pthost.cpp include/pthost.h include/ptgpu.h $(CSRC)/cie_data.inc
 	mkdir -p $(LIB)
-	$(CXX) -O2 -std=c++17 -fPIC -ffp-contract=off -Wall -shared -o $@ $(PKG)/host/pthost.cpp -ldl
+	$(CXX) -O2 -std=c++17 -fPIC -ffp-contract=off -Wall -shared -o $@ $(PKG)/host/pthost.cpp -ldl -lz
 
 $(LIB)/pt: $(PKG)/host/pt_main.cpp $(LIB)/libpthost.so $(LIB)/libptgpu.so
 	$(CXX) -O2 -std=c++17 -Wall -o $@ $(PKG)/host/pt_main.cpp -L$(LIB) -lpthost -lptgpu -Wl,-rpath,'$$ORIGIN'

@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <zlib.h>
 #include <map>
 #include <memory>
 #include <sstream>
@@ -534,6 +535,70 @@ MeshData parse_ply(const std::string& data) {
 
 // parse_obj (parser/mod.rs:1258-1303): one object/group of triangles "f p/t/n p/t/n p/t/n"; winding fixed so that
 // the geometric normal agrees with the summed vertex normals.
+// parse_serialized + get_offset (parser/mod.rs:1305-1412): Mitsuba's .serialized container, version 3, single precision.
+// File = meshes back to back, each {u16 magic, u16 version, zlib stream}, then a table of u32 offsets and the u32 mesh
+// count at the very end. The stream: u32 flags, u64 n_vertices, u64 n_triangles, positions, [normals], [texcoords],
+// [colours], u32 index triples. No shipped scene uses the format: checked against files written to that layout only.
+MeshData parse_serialized(const std::string& data, uint32_t shape_index) {
+    auto u32_at = [&](size_t at) {
+        if (at + 4 > data.size()) die("serialized: truncated file");
+        uint32_t v;
+        memcpy(&v, data.data() + at, 4);
+        return v;
+    };
+    if (data.size() < 8) die("serialized: truncated file");
+    uint16_t version;
+    memcpy(&version, data.data() + 2, 2);
+    if (version != 3) die("serialized: only version 3 files are read (parser/mod.rs:1404)");
+    const uint32_t n_shapes = u32_at(data.size() - 4);
+    if (shape_index >= n_shapes) die("serialized: shape_index beyond the file's mesh count");
+    const size_t table = data.size() - 4 * (size_t)(n_shapes - shape_index + 1);
+    if (4 * (size_t)(n_shapes + 1) > data.size()) die("serialized: truncated offset table");
+    const size_t offset = (size_t)u32_at(table) + 4;  // past magic and version
+    if (offset >= data.size()) die("serialized: mesh offset beyond the file");
+    z_stream zs{};
+    if (inflateInit(&zs) != Z_OK) die("serialized: zlib initialisation failed");
+    zs.next_in = reinterpret_cast<Bytef*>(const_cast<char*>(data.data() + offset));
+    zs.avail_in = (uInt)std::min<size_t>(data.size() - offset, 0xffffffffu);
+    auto read = [&](void* dst, size_t n) {
+        zs.next_out = reinterpret_cast<Bytef*>(dst);
+        while (n > 0) {
+            zs.avail_out = (uInt)std::min<size_t>(n, 1u << 30);
+            const uInt want = zs.avail_out;
+            const int rc = inflate(&zs, Z_NO_FLUSH);
+            const uInt got = want - zs.avail_out;
+            n -= got;
+            if (n > 0 && (rc == Z_STREAM_END || (rc != Z_OK && rc != Z_BUF_ERROR) || got == 0)) {
+                inflateEnd(&zs);
+                die("serialized: truncated or corrupt zlib stream");
+            }
+        }
+    };
+    uint32_t flags;
+    uint64_t n_vertices, n_triangles;
+    read(&flags, 4);
+    read(&n_vertices, 8);
+    read(&n_triangles, 8);
+    if (flags & 0x2000u) { inflateEnd(&zs); die("serialized: double precision meshes are not read (parser/mod.rs:1327)"); }
+    if (n_vertices > 0x7fffffffull || n_triangles > 0x7fffffffull) { inflateEnd(&zs); die("serialized: implausible mesh size"); }
+    MeshData m;
+    m.points.resize(3 * n_vertices);
+    read(m.points.data(), 12 * n_vertices);
+    if (flags & 0x0001u) {
+        m.normals.resize(3 * n_vertices);
+        read(m.normals.data(), 12 * n_vertices);
+    }
+    std::vector<float> skip;
+    if (flags & 0x0002u) { skip.resize(2 * n_vertices); read(skip.data(), 8 * n_vertices); }
+    if (flags & 0x0008u) { skip.resize(3 * n_vertices); read(skip.data(), 12 * n_vertices); }
+    m.tris.resize(3 * n_triangles);
+    read(m.tris.data(), 12 * n_triangles);
+    inflateEnd(&zs);
+    for (uint32_t i : m.tris)
+        if (i >= n_vertices) die("serialized: vertex index out of range");
+    return m;
+}
+
 MeshData parse_obj(const std::string& path) {
     std::istringstream in(read_file(path));
     MeshData m;
@@ -867,6 +932,7 @@ pthost_scene* load_scene(const char* collection, const char* name, const char* o
             const std::string& type = L.attr(n, "type");
             std::string filename;
             bool face_normals = false;
+            uint32_t shape_index = 0;
             if (type == "rectangle") {
                 sh.mesh.points = {-1, -1, 0, 1, -1, 0, 1, 1, 0, -1, 1, 0};
                 sh.mesh.tris = {2, 1, 0, 0, 3, 2};
@@ -877,7 +943,6 @@ pthost_scene* load_scene(const char* collection, const char* name, const char* o
                 sh.mesh = parse_ply(read_file(L.data_dir + "/icosphere_6.ply"));
             } else if (type == "obj" || type == "ply") {
             } else if (type == "serialized") {
-                die("shape type 'serialized' is not supported by this host (SURVEY.md §8f-1)");
             } else
                 die("unknown shape type: " + type);
             for (auto& c : n.children) {
@@ -889,7 +954,8 @@ pthost_scene* load_scene(const char* collection, const char* name, const char* o
                     for (auto& cc : c->children)
                         if (cc->tag == "rgb" && L.attr(*cc, "name") == "radiance") parse_array3(L.attr(*cc, "value"), sh.radiance);
                 } else if (c->tag == "ref") sh.refs.push_back(L.attr(*c, "id"));
-                else if (c->tag == "string" && L.attr(*c, "name") == "filename" && (type == "obj" || type == "ply")) filename = L.attr(*c, "value");
+                else if (c->tag == "string" && L.attr(*c, "name") == "filename" && (type == "obj" || type == "ply" || type == "serialized")) filename = L.attr(*c, "value");
+                else if (c->tag == "integer" && L.attr(*c, "name") == "shape_index" && type == "serialized") shape_index = (uint32_t)std::stoul(L.attr(*c, "value"));
                 else if (c->tag == "boolean" && L.attr(*c, "name") == "face_normals" && type == "obj") face_normals = L.attr(*c, "value") == "true";
                 else if (type == "sphere" && c->tag == "float" && L.attr(*c, "name") == "radius") {
                     const float r = parse_f32(L.attr(*c, "value"));
@@ -904,6 +970,8 @@ pthost_scene* load_scene(const char* collection, const char* name, const char* o
                 if (face_normals) sh.mesh.normals.clear();
             } else if (type == "ply") {
                 sh.mesh = parse_ply(read_file(L.root + "/" + filename));
+            } else if (type == "serialized") {
+                sh.mesh = parse_serialized(read_file(L.root + "/" + filename), shape_index);
             }
             shapes.push_back(std::move(sh));
         } else if (n.tag == "emitter") {

@@ -317,8 +317,9 @@ def test_loader_errors_are_reported_not_fatal():
 
 
 def test_loader_reads_ply_and_obj_files(tmp_path):
-    """`<shape type="ply">` (ascii and binary little-endian, with and without normals; parser/mod.rs:1173-1256) and
-    `<shape type="obj">` from files next to the scene, with the shape's to_world applied."""
+    """`<shape type="ply">` (ascii and binary little-endian, with and without normals; parser/mod.rs:1173-1256),
+    `<shape type="obj">` and `<shape type="serialized">` (second mesh of a two-mesh file) from files next to the scene,
+    with the shape's to_world applied."""
     import struct
     scene = tmp_path / "filemesh"
     scene.mkdir()
@@ -333,6 +334,20 @@ def test_loader_reads_ply_and_obj_files(tmp_path):
     body = b"".join(struct.pack("<6f", x, y, z, 0.0, 0.0, 1.0) for x, y, z in verts) + b"".join(struct.pack("<B3I", 3, a, b, c) for a, b, c in faces)
     (scene / "quad_bin.ply").write_bytes(header + body)
     (scene / "quad.obj").write_text("".join(f"v {x} {y} {z}\n" for x, y, z in verts) + "vn 0 0 1\n" * 4 + "f 1//1 2//2 3//3\nf 1//1 3//3 4//4\n")  # one normal per position (parser/mod.rs:1297)
+    # Mitsuba .serialized, version 3 (parser/mod.rs:1305-1412): two meshes, the second one is the quad (with normals)
+    import zlib
+
+    def ser_mesh(vs, fs, normals):
+        flags = 0x1000 | (0x0001 if normals else 0)
+        raw = struct.pack("<IQQ", flags, len(vs), len(fs)) + b"".join(struct.pack("<3f", *v) for v in vs)
+        if normals:
+            raw += b"".join(struct.pack("<3f", 0.0, 0.0, 1.0) for _ in vs)
+        raw += b"".join(struct.pack("<3I", *f) for f in fs)
+        return struct.pack("<HH", 0x041C, 3) + zlib.compress(raw)
+    m0, m1 = ser_mesh([(0, 0, 0), (1, 0, 0), (0, 1, 0)], [(0, 1, 2)], False), ser_mesh(verts, faces, True)
+    (scene / "two.serialized").write_bytes(m0 + m1 + struct.pack("<III", 0, len(m0), 2))
+    ser_shape = ('<shape type="serialized"><string name="filename" value="two.serialized"/><integer name="shape_index" value="1"/>'
+                 '<transform name="to_world"><scale value="2"/><translate value="30, 0, 0"/></transform><ref id="M"/></shape>')
     shape = lambda kind, fn, dx: (f'<shape type="{kind}"><string name="filename" value="{fn}"/><transform name="to_world"><scale value="2"/>'
                                   f'<translate value="{dx}, 0, 0"/></transform><ref id="M"/></shape>')
     (scene / "scene_v3.xml").write_text(
@@ -341,19 +356,19 @@ def test_loader_reads_ply_and_obj_files(tmp_path):
         '<sampler type="independent"><integer name="sample_count" value="4"/></sampler>'
         '<film type="hdrfilm"><integer name="width" value="32"/><integer name="height" value="32"/></film></sensor>'
         '<bsdf type="diffuse" id="M"><rgb name="reflectance" value="0.5, 0.5, 0.5"/></bsdf>'
-        + shape("ply", "quad_ascii.ply", 0) + shape("ply", "quad_bin.ply", 10) + shape("obj", "quad.obj", 20) + "</scene>")
+        + shape("ply", "quad_ascii.ply", 0) + shape("ply", "quad_bin.ply", 10) + shape("obj", "quad.obj", 20) + ser_shape + "</scene>")
     sc = pt.LoadedScene("filemesh", collection=tmp_path)
     d = sc.pointer().contents
-    assert d.n_meshes == 3
+    assert d.n_meshes == 4
     los = []
-    for m in range(3):
+    for m in range(4):
         mesh = d.meshes[m]
         assert mesh.n_triangles == 2 and mesh.n_points >= 4
         P = np.ctypeslib.as_array(mesh.points, shape=(mesh.n_points, 3))
         assert np.allclose(P.max(axis=0) - P.min(axis=0), [2, 2, 0])   # the unit quad, scaled by 2
         los.append(P[:, 0].min())
-    assert sorted(np.round(los).tolist()) == [0.0, 10.0, 20.0]             # each shape's own translation
-    has_normals = [bool(d.meshes[m].normals) for m in range(3)]
+    assert sorted(np.round(los).tolist()) == [0.0, 10.0, 20.0, 30.0]       # each shape's own translation
+    has_normals = [bool(d.meshes[m].normals) for m in range(4)]
     assert has_normals.count(True) >= 1 and has_normals.count(False) >= 1   # the ascii file carries none
 
 
