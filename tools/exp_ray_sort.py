@@ -28,3 +28,10 @@ octant = (bounce[:, 3] < 0) * 1 + (bounce[:, 4] < 0) * 2 + (bounce[:, 5] < 0) * 
 key = (octant << 9) | (cell[:, 0] << 6) | (cell[:, 1] << 3) | cell[:, 2]
 srt = bounce[np.argsort(key, kind="stable")]
 ctx.trace(srt)                                      # dispatch B: grouped
+
+# dispatch C: only what a 256-thread workgroup could do while it writes its rays: octant order within chunks of 256
+idx = np.arange(m)
+local = np.lexsort((octant, idx // 256))
+ctx.trace(bounce[local])
+# dispatch D: the same within chunks of 1024
+ctx.trace(bounce[np.lexsort((octant, idx // 1024))])
