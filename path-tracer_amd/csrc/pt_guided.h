@@ -576,17 +576,24 @@ __global__ __launch_bounds__(kBlock) void k_raygen_guided(SceneDev sc, CameraDev
 // when the surface has been shaded (emitted light, the direct-light sample) goes into the vertex's row at once —
 // harmless if the vertex is not stored after all, the row stays beyond the path's count — the sampled direction
 // later. The direct-light sample is written as if visible; k_occlude_guided clears it when the shadow ray is blocked.
-PT_D void store_vertex_light(const GuidedParams& gp, uint32_t row, uint32_t pid, const Spec& e, const Spec& li) {
+// The emitted light of a vertex is zero unless the path has just hit an emitter, its direct light is zero when no light
+// sample was made: each one's 32 bytes are written, and later added by the record pass, only when present (`has_emitted`,
+// `has_li`: bits 0 and 1 of the line's spare word, which store_vertex writes).
+PT_D void store_vertex_light(const GuidedParams& gp, uint32_t row, uint32_t pid, const Spec& e, const Spec& li, bool has_emitted, bool has_li) {
     float4* v = gp.vtx.at(row, pid);
-    v[VTX_E0] = make_float4(e.v[0], e.v[1], e.v[2], e.v[3]);
-    v[VTX_E1] = make_float4(e.v[4], e.v[5], e.v[6], e.v[7]);
-    v[VTX_LI0] = make_float4(li.v[0], li.v[1], li.v[2], li.v[3]);
-    v[VTX_LI1] = make_float4(li.v[4], li.v[5], li.v[6], li.v[7]);
+    if (has_emitted) {
+        v[VTX_E0] = make_float4(e.v[0], e.v[1], e.v[2], e.v[3]);
+        v[VTX_E1] = make_float4(e.v[4], e.v[5], e.v[6], e.v[7]);
+    }
+    if (has_li) {
+        v[VTX_LI0] = make_float4(li.v[0], li.v[1], li.v[2], li.v[3]);
+        v[VTX_LI1] = make_float4(li.v[4], li.v[5], li.v[6], li.v[7]);
+    }
 }
-PT_D void store_vertex(const GuidedParams& gp, uint32_t row, uint32_t pid, V3 p, V3 wi, float pdf, const Spec& f) {
+PT_D void store_vertex(const GuidedParams& gp, uint32_t row, uint32_t pid, V3 p, V3 wi, float pdf, const Spec& f, bool has_emitted, bool has_li) {
     float4* v = gp.vtx.at(row, pid);
     v[VTX_P_PDF] = make_float4(p.x, p.y, p.z, pdf);
-    v[VTX_WI] = make_float4(wi.x, wi.y, wi.z, 0.0f);
+    v[VTX_WI] = make_float4(wi.x, wi.y, wi.z, u2f((has_emitted ? 1u : 0u) | (has_li ? 2u : 0u)));
     v[VTX_F0] = make_float4(f.v[0], f.v[1], f.v[2], f.v[3]);
     v[VTX_F1] = make_float4(f.v[4], f.v[5], f.v[6], f.v[7]);
 }
@@ -628,8 +635,8 @@ __global__ __launch_bounds__(kBlock, KINDS != 7 ? PT_GUIDED_DIFFUSE_WAVES : PT_S
             if (prim == kNoHit) {
                 // miss vertex (mod.rs:140-150): far point along the ray, nothing emitted without an envmap
                 if (nverts < gp.n_rows) {
-                    store_vertex_light(gp, nverts, pid, spec_splat(0.0f), spec_splat(0.0f));
-                    store_vertex(gp, nverts, pid, o + d * 10000.0f, d, 1.0f, spec_splat(1.0f));
+                    store_vertex_light(gp, nverts, pid, spec_splat(0.0f), spec_splat(0.0f), false, false);
+                    store_vertex(gp, nverts, pid, o + d * 10000.0f, d, 1.0f, spec_splat(1.0f), false, false);
                     nverts++;
                 }
                 ended = true;
@@ -715,7 +722,8 @@ __global__ __launch_bounds__(kBlock, KINDS != 7 ? PT_GUIDED_DIFFUSE_WAVES : PT_S
                             }
                         }
                     }
-                    if (!specular && nverts < gp.n_rows) store_vertex_light(gp, nverts, pid, emitted, contrib);
+                    const bool has_emitted = !spec_is_black(emitted);
+                    if (!specular && nverts < gp.n_rows) store_vertex_light(gp, nverts, pid, emitted, contrib, has_emitted, has_nee);
                     PT_TICK(2);
                     BsdfSample bs;
                     const bool ok = guider_sample(tree, bsdf, sf.frame, sf.ng, wo, rng, sm_scales + threadIdx.x, sampler_word, root, bs PT_DBG_ARGS);
@@ -733,7 +741,7 @@ __global__ __launch_bounds__(kBlock, KINDS != 7 ? PT_GUIDED_DIFFUSE_WAVES : PT_S
 #pragma unroll
                         for (int k = 0; k < NSW; k++) fw.v[k] = bs.f.v[k] / bs.pdf;
                         if (!specular && nverts < gp.n_rows) {
-                            store_vertex(gp, nverts, pid, p, bs.wi, bs.pdf, fw);
+                            store_vertex(gp, nverts, pid, p, bs.wi, bs.pdf, fw, has_emitted, has_nee);
                             shadow_row = nverts;
                             want_shadow = has_nee;
                             nverts++;
@@ -857,8 +865,8 @@ __global__ __launch_bounds__(kBlock) void k_guide_scan(SceneDev sc, RenderParams
                     u2 = rng_f32(rng);
                 }
                 l = l * spec_from(vx[VTX_F0], vx[VTX_F1]);
-                l = l + spec_from(vx[VTX_LI0], vx[VTX_LI1]);
-                l = l + spec_from(vx[VTX_E0], vx[VTX_E1]);
+                if (f2u(wi.w) & 2u) l = l + spec_from(vx[VTX_LI0], vx[VTX_LI1]);
+                if (f2u(wi.w) & 1u) l = l + spec_from(vx[VTX_E0], vx[VTX_E1]);
             }
             const unsigned long long m = __ballot(want);
             if (m != 0ull) {
