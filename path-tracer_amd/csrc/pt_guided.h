@@ -562,12 +562,12 @@ __global__ __launch_bounds__(kBlock) void k_raygen_guided(SceneDev sc, CameraDev
             V3 o, d;
             camera_sample_we(cam, ix, iy, u0, u1, o, d);
             const uint32_t lam = index_in_tile(pixel, cam.resx) + (pass == 0 ? 0u : 256u);
-            st.o_pdf[slot] = make_float4(o.x, o.y, o.z, 0.0f);
+            st.o_pdf[slot] = make_float4(o.x, o.y, o.z, u2f(slot));  // w: path id (vertex-store column); the previous vertex' point
+                                                                     // and pdf, which `path` keeps here, are read back from its line
             st.d_flags[slot] = make_float4(d.x, d.y, d.z, u2f(0u));
             st.beta0[slot] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
             st.beta1[slot] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
             st.rng_px[slot] = make_uint4((uint32_t)rng.state, (uint32_t)(rng.state >> 32), pixel, lam);  // w: lambda index | nverts << 16
-            st.prev_p[slot] = make_float4(0.0f, 0.0f, 0.0f, u2f(slot));                                  // w: path id (vertex-store column)
         }
     }
 }
@@ -614,20 +614,17 @@ __global__ __launch_bounds__(kBlock, KINDS != 7 ? PT_GUIDED_DIFFUSE_WAVES : PT_S
         const uint32_t i = it * stride + blockIdx.x * blockDim.x + threadIdx.x;
         const bool valid = i < n;
         bool alive = false, want_shadow = false, shaded = false, skipped_shadow = false, ended = false;
-        V3 o = mk3(0, 0, 0), d = mk3(0, 0, 1), prev_p = mk3(0, 0, 0), sh_from = mk3(0, 0, 0), sh_to = mk3(0, 0, 0);
-        float prev_pdf = 0.0f;
+        V3 o = mk3(0, 0, 0), d = mk3(0, 0, 1), sh_from = mk3(0, 0, 0), sh_to = mk3(0, 0, 0);
         uint32_t flags = 0, pid = 0, nverts = 0, shadow_row = 0;
         Spec beta = spec_splat(0.0f);
         uint4 rp4 = make_uint4(0, 0, 0, 0);
         if (valid) {
-            const float4 o4 = in.o_pdf[i], d4 = in.d_flags[i], pp = in.prev_p[i];
+            const float4 o4 = in.o_pdf[i], d4 = in.d_flags[i];
             o = mk3(o4.x, o4.y, o4.z);
             d = mk3(d4.x, d4.y, d4.z);
-            prev_pdf = o4.w;
             flags = f2u(d4.w);
             rp4 = in.rng_px[i];
-            prev_p = mk3(pp.x, pp.y, pp.z);
-            pid = f2u(pp.w);
+            pid = f2u(o4.w);
             nverts = rp4.w >> 16;
             const uint2 prim_tag = hit.prim[i];
             const uint32_t prim = prim_tag.x;
@@ -665,8 +662,11 @@ __global__ __launch_bounds__(kBlock, KINDS != 7 ? PT_GUIDED_DIFFUSE_WAVES : PT_S
                         const bool direct = (depth == 0) || spec_bounce;
                         if (rp.mode == MODE_PT || direct) emitted = light_emitted(rp.spec, sf.tri, sf.ng, p, o, row);
                         else if (rp.mode == MODE_MIS) {
-                            const float pb = prev_pdf;
-                            const float pl = light_pdf_li(sf.tri, sf.ng, prev_p, p);
+                            // previous point and its sampling pdf: the last stored vertex (the previous bounce was not
+                            // specular, or this would be `direct`; every non-specular bounce is stored)
+                            const float4 pv = nverts > 0 ? gp.vtx.at(nverts - 1, pid)[VTX_P_PDF] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                            const float pb = pv.w;
+                            const float pl = light_pdf_li(sf.tri, sf.ng, mk3(pv.x, pv.y, pv.z), p);
                             const float w = (pb * pb) / (pb * pb + pl * pl);
                             emitted = w * light_emitted(rp.spec, sf.tri, sf.ng, p, o, row);
                         }
@@ -753,8 +753,6 @@ __global__ __launch_bounds__(kBlock, KINDS != 7 ? PT_GUIDED_DIFFUSE_WAVES : PT_S
                             if (bs.terminate_secondary) flags |= FLAG_SECONDARY_TERMINATED;
                             o = offset_ray_origin(sf.blo, sf.bhi, sf.ng, bs.wi);
                             d = bs.wi;
-                            prev_p = p;
-                            prev_pdf = bs.pdf;
                             depth += 1;
                             flags = (flags & ~FLAG_DEPTH_MASK) | (depth & FLAG_DEPTH_MASK);
                             alive = depth < rp.max_depth;
@@ -772,11 +770,10 @@ __global__ __launch_bounds__(kBlock, KINDS != 7 ? PT_GUIDED_DIFFUSE_WAVES : PT_S
         n_shaded += shaded ? 1u : 0u;
         n_skipped += skipped_shadow ? 1u : 0u;
         if (alive) {
-            out.o_pdf[a_slot] = make_float4(o.x, o.y, o.z, prev_pdf);
+            out.o_pdf[a_slot] = make_float4(o.x, o.y, o.z, u2f(pid));
             out.d_flags[a_slot] = make_float4(d.x, d.y, d.z, u2f(flags));
             store_spec(out.beta0, out.beta1, a_slot, beta);
             out.rng_px[a_slot] = rp4;
-            out.prev_p[a_slot] = make_float4(prev_p.x, prev_p.y, prev_p.z, u2f(pid));
         }
         if (valid && ended) {
             gp.tail.rng_px[pid] = rp4;
