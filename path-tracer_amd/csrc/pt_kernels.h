@@ -11,6 +11,9 @@ namespace pt {
 #ifndef PT_SHADE_WAVES
 #define PT_SHADE_WAVES 2  // minimum waves per SIMD the shade kernels are compiled for (register budget 512 / N)
 #endif
+#ifndef PT_PATH_DIFFUSE_WAVES
+#define PT_PATH_DIFFUSE_WAVES 3  // k_shade_path without conductors: 3 waves per SIMD fit (171 registers otherwise, one too many)
+#endif
 
 // One atomic per wave: lanes with `want` get consecutive indices from *counter.
 PT_D uint32_t wave_alloc(uint32_t* counter, bool want) {
@@ -288,7 +291,7 @@ __global__ __launch_bounds__(kBlock) void k_occluded_batch(SceneDev sc, const fl
 // ------------------------------------------------------------------ shade: `path` integrator
 // One iteration of PathIntegrator::li's loop body after the intersection (path_tracer.rs:69-180).
 template <int KINDS>
-__global__ __launch_bounds__(kBlock, PT_SHADE_WAVES) void k_shade_path(SceneDev sc, RenderParams rp, PathCols in, HitCols hit, PathCols out, ShadowCols sh,
+__global__ __launch_bounds__(kBlock, KINDS != 7 ? PT_PATH_DIFFUSE_WAVES : PT_SHADE_WAVES) void k_shade_path(SceneDev sc, RenderParams rp, PathCols in, HitCols hit, PathCols out, ShadowCols sh,
                                                        const RoundCounters* cur, RoundCounters* nxt) {
     __shared__ BlockAlloc sm_alloc;
     __shared__ uint32_t sm_count;
