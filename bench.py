@@ -49,6 +49,13 @@ def main() -> int:
     ap.add_argument("--census", action="store_true", help="also count BVH nodes/triangles per ray (extra untimed render)")
     args = ap.parse_args()
 
+    # The contract is ONE JSON line on stdout. Native libraries write banners there too (RCCL prints its version block
+    # on rank 0 at communicator creation), so file descriptor 1 points at stderr for the whole run and the result line is
+    # written to the saved descriptor at the very end.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
 
@@ -237,7 +244,8 @@ def main() -> int:
                    "mrays_per_s": round(mrays, 1), "stree_nodes": st.get("stree_nodes", 0), "dtree_nodes": st.get("dtree_nodes", 0)},
         "roofline": roofline, "cpu_baseline": cpu, "relmse_vs_cpu_oracle": relmse,
     }
-    print(json.dumps(out))
+    sys.stdout.flush()
+    os.write(result_fd, (json.dumps(out) + "\n").encode())
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

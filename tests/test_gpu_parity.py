@@ -433,5 +433,7 @@ def test_bench_rccl_path_rehearsal(workload):
     r = subprocess.run([sys.executable, str(Path(__file__).resolve().parent.parent / "bench.py"), "--workload", workload, "--steps", "1", "--warmup", "0",
                         "--spp", "16", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=280)
     assert r.returncode == 0, r.stderr[-2000:]
-    line = json.loads(r.stdout.strip().splitlines()[-1])
+    lines = r.stdout.strip().splitlines()
+    assert len(lines) == 1, lines  # ONE JSON line on stdout: RCCL's banner and the like go to stderr
+    line = json.loads(lines[0])
     assert line["n_gpus"] == 1 and line["value"] > 0 and line["roofline"]["achieved"] > 0
