@@ -250,6 +250,7 @@ struct HitOut {
     uint32_t mesh_index, triangle_index, leaf_index, hit;
     float t, b0, b1, b2;
 };
+template <bool COUNT>  // COUNT: the instrumented walk (nodes popped, triangles tested), as the census variants of the stages
 __global__ __launch_bounds__(kBlock) void k_trace_batch(SceneDev sc, const float* rays, uint32_t n, HitOut* out, unsigned long long* counts) {
     bvh_stage_nodes(sc);
     const uint32_t stride = gridDim.x * blockDim.x;
@@ -257,7 +258,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_batch(SceneDev sc, const float
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const float* r = rays + 7 * (size_t)i;
         uint32_t a = 0, b = 0;
-        const Hit h = bvh_intersect<true>(sc, mk3(r[0], r[1], r[2]), mk3(r[3], r[4], r[5]), r[6], &a, &b);
+        const Hit h = bvh_intersect<COUNT>(sc, mk3(r[0], r[1], r[2]), mk3(r[3], r[4], r[5]), r[6], &a, &b);
         nn += a;
         nt += b;
         HitOut o;
@@ -273,7 +274,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_batch(SceneDev sc, const float
         }
         out[i] = o;
     }
-    if (counts) {
+    if (COUNT && counts) {
         atomicAdd(counts + 0, nn);
         atomicAdd(counts + 1, nt);
     }

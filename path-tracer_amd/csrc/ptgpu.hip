@@ -522,10 +522,20 @@ int ptgpu_trace_batch(ptgpu_ctx* c, const float* rays, uint32_t n, ptgpu_hit* hi
     HIP_TRY(d_rays.alloc(7 * (size_t)n));
     HIP_TRY(d_hits.alloc(n));
     HIP_TRY(hipMemcpyAsync(d_rays.p, rays, 7 * (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(k_trace_batch, dim3(grid_for(c, n)), dim3(kBlock), c->bvh_lds, c->stream, c->scene, d_rays.p, n, d_hits.p, (unsigned long long*)nullptr);
+    // Also the extend micro-benchmark (tools/bench_extend.py): with profiling on, the walk's own time lands in
+    // the EXTEND stage (ptgpu_kernel_times); with the census on, nodes popped / triangles tested land in ptgpu_census[0..1].
+    reset_stage_times(c);
+    {
+        StageTimer st(c, PTGPU_STAGE_EXTEND);
+        if (c->census_on)
+            hipLaunchKernelGGL(k_trace_batch<true>, dim3(grid_for(c, n)), dim3(kBlock), c->bvh_lds, c->stream, c->scene, d_rays.p, n, d_hits.p, c->d_census.p);
+        else
+            hipLaunchKernelGGL(k_trace_batch<false>, dim3(grid_for(c, n)), dim3(kBlock), c->bvh_lds, c->stream, c->scene, d_rays.p, n, d_hits.p, (unsigned long long*)nullptr);
+    }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(hits_out, d_hits.p, (size_t)n * sizeof(HitOut), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    resolve_stage_times(c);
     return PTGPU_OK;
 }
 
