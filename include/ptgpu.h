@@ -152,7 +152,9 @@ int ptgpu_guided_selfcheck(ptgpu_ctx* ctx, uint32_t n_probes, uint64_t seed, uin
 
 /* Parity hooks (no reference counterpart as an API; they expose Scene::intersect_t -> Bvh::intersect,
  * pt/src/bvh.rs:86-142, and Scene::occluded, pt/src/scene.rs:229-235, on caller-supplied rays).
- * rays: n * 7 floats (ox,oy,oz, dx,dy,dz, t_max). */
+ * rays: n * 7 floats (ox,oy,oz, dx,dy,dz, t_max).
+ * ptgpu_trace_batch doubles as the extend micro-benchmark: it resets the stage timers, and with profiling on reports the
+ * walk kernel's time as PTGPU_STAGE_EXTEND; with the census on it adds nodes popped / triangles tested to census[0..1]. */
 int ptgpu_trace_batch(ptgpu_ctx* ctx, const float* rays, uint32_t n, ptgpu_hit* hits_out);
 /* from/to: n * 3 floats each; out[i] = 1 if Scene::occluded(from_i, to_i). */
 int ptgpu_occluded_batch(ptgpu_ctx* ctx, const float* from, const float* to, uint32_t n, uint8_t* out);

@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -141,6 +142,7 @@ struct ptgpu_ctx {
     std::vector<int> ev_stage;  // stage of pair i (events 2i, 2i+1)
     bool census_on = false;
     int kinds = 7;       // material kinds in use, rounded up to a compiled set (PT_LAUNCH_BY_KINDS)
+    std::map<const void*, int> resident_blocks;  // per shade kernel: workgroups resident per CU (resident_grid)
     size_t bvh_lds = 0;  // dynamic LDS bytes of every kernel that walks the BVH (pt_device.h: bvh_intersect)
     DevBuf<unsigned long long> d_census;  // extend nodes, extend tris, occlude nodes, occlude tris
     double stage_ms[PTGPU_N_STAGES] = {0, 0, 0, 0, 0, 0};
@@ -153,12 +155,27 @@ struct ptgpu_ctx {
 namespace {
 
 // Shade kernels are compiled for three material-kind sets: diffuse only (1), diffuse + dielectric (3), all (7).
+// The shade kernels hold 2-4 workgroups per CU (registers), not the 8 the stage grid is sized for: they are launched with
+// exactly as many workgroups as are resident at once, so the grid-stride loop has no second, partly filled round (a 3-wave
+// kernel runs 3 + 3 + 2 otherwise: measured 3-4 % of the kernel on the Cornell box, 4 blocks per CU 17 % slower than 3).
+#define PT_LAUNCH_ONE_KIND(c, kernel, grid, ...)                                                                          \
+    hipLaunchKernelGGL(kernel, dim3(resident_grid((c), (const void*)kernel, (grid))), dim3(kBlock), 0, (c)->stream, __VA_ARGS__)
 #define PT_LAUNCH_BY_KINDS(c, kernel, grid, ...)                                                                        \
     do {                                                                                                                 \
-        if ((c)->kinds == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(kernel<1>), dim3(grid), dim3(kBlock), 0, (c)->stream, __VA_ARGS__);      \
-        else if ((c)->kinds == 3) hipLaunchKernelGGL(HIP_KERNEL_NAME(kernel<3>), dim3(grid), dim3(kBlock), 0, (c)->stream, __VA_ARGS__); \
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(kernel<7>), dim3(grid), dim3(kBlock), 0, (c)->stream, __VA_ARGS__);                      \
+        if ((c)->kinds == 1) PT_LAUNCH_ONE_KIND(c, HIP_KERNEL_NAME(kernel<1>), grid, __VA_ARGS__);                       \
+        else if ((c)->kinds == 3) PT_LAUNCH_ONE_KIND(c, HIP_KERNEL_NAME(kernel<3>), grid, __VA_ARGS__);                  \
+        else PT_LAUNCH_ONE_KIND(c, HIP_KERNEL_NAME(kernel<7>), grid, __VA_ARGS__);                                       \
     } while (0)
+
+int resident_grid(ptgpu_ctx* c, const void* kernel, int grid) {
+    auto it = c->resident_blocks.find(kernel);
+    if (it == c->resident_blocks.end()) {
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, 0) != hipSuccess || per_cu < 1) per_cu = 8;
+        it = c->resident_blocks.emplace(kernel, std::min(per_cu, 8)).first;
+    }
+    return std::min(grid, c->n_cus * it->second);
+}
 
 int grid_for(const ptgpu_ctx* c, uint64_t n) {
     const uint64_t want = (n + kBlock - 1) / kBlock;
