@@ -794,8 +794,9 @@ __global__ __launch_bounds__(kBlock, KINDS != 7 ? PT_GUIDED_DIFFUSE_WAVES : PT_S
 // NEE visibility for the guided walk: shade wrote the sample into the vertex as if visible; a blocked one is cleared.
 template <bool CENSUS>
 __global__ __launch_bounds__(kBlock) void k_occlude_guided(SceneDev sc, GuidedParams gp, ShadowCols sh, const RoundCounters* cnt, unsigned long long* census) {
-    bvh_stage_nodes(sc);
     const uint32_t n = cnt->n_shadow;
+    if (blockIdx.x * blockDim.x >= n) return;  // late rounds: most workgroups have nothing to do, not even staging nodes
+    bvh_stage_nodes(sc);
     const uint32_t stride = gridDim.x * blockDim.x;
     uint32_t cn = 0, ct = 0;
     for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) {

@@ -231,8 +231,9 @@ __global__ __launch_bounds__(kBlock) void k_raygen_camera(SceneDev sc, CameraDev
 // Scene::intersect -> Bvh::intersect (scene.rs:184-186, bvh.rs:86-142) for slots [0, n_active).
 template <bool CENSUS>
 __global__ __launch_bounds__(kBlock, 8) void k_extend(SceneDev sc, PathCols st, HitCols hit, const RoundCounters* cnt, unsigned long long* census) {
-    bvh_stage_nodes(sc);
     const uint32_t n = cnt->n_active;
+    if (blockIdx.x * blockDim.x >= n) return;  // late rounds: most workgroups have nothing to do, not even staging nodes
+    bvh_stage_nodes(sc);
     const uint32_t stride = gridDim.x * blockDim.x;
     uint32_t cn = 0, ct = 0;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
@@ -444,8 +445,9 @@ __global__ __launch_bounds__(kBlock, KINDS != 7 ? PT_PATH_DIFFUSE_WAVES : PT_SHA
 // radiance and finishes paths that ended in shade with this ray still pending.
 template <bool CENSUS>
 __global__ __launch_bounds__(kBlock, 8) void k_occlude_path(SceneDev sc, RenderParams rp, PathCols st, ShadowCols sh, const RoundCounters* cnt, unsigned long long* census) {
-    bvh_stage_nodes(sc);
     const uint32_t n = cnt->n_shadow;
+    if (blockIdx.x * blockDim.x >= n) return;  // late rounds: most workgroups have nothing to do, not even staging nodes
+    bvh_stage_nodes(sc);
     const uint32_t stride = gridDim.x * blockDim.x;
     uint32_t cn = 0, ct = 0;
     for (uint32_t base = blockIdx.x * blockDim.x; base < n; base += stride) {  // block-uniform trip count
@@ -639,8 +641,9 @@ __global__ __launch_bounds__(kBlock, PT_SHADE_WAVES) void k_shade_light(SceneDev
 // Camera-connection visibility + Film::add_splat (camera.rs:161-166) with f64 atomics.
 template <bool CENSUS>
 __global__ __launch_bounds__(kBlock) void k_occlude_splat(SceneDev sc, RenderParams rp, ShadowCols sh, const RoundCounters* cnt, unsigned long long* census) {
-    bvh_stage_nodes(sc);
     const uint32_t n = cnt->n_shadow;
+    if (blockIdx.x * blockDim.x >= n) return;  // late rounds: most workgroups have nothing to do, not even staging nodes
+    bvh_stage_nodes(sc);
     const uint32_t stride = gridDim.x * blockDim.x;
     const double* r = reinterpret_cast<const double*>(sh.q2);
     uint32_t cn = 0, ct = 0;
