@@ -848,22 +848,25 @@ __global__ __launch_bounds__(kBlock) void k_guide_scan(SceneDev sc, RenderParams
         Spec l = spec_splat(0.0f);
         const size_t base = (size_t)chunk * kBlock * gp.n_rows;
         // The lines of a path are read back to front, and nothing in a line's address depends on the line before it: the
-        // next line's unconditional half is requested before this one is folded in (two lines in flight per lane).
-        float4 n_pp = make_float4(0, 0, 0, 0), n_wi = n_pp, n_f0 = n_pp, n_f1 = n_pp;
+        // next line is requested whole before this one is folded in (two lines in flight per lane). Whole, because a
+        // half asked for one trip later has left L2 by then and comes from HBM a second time (measured: +24 % traffic).
+        float4 nx[8];
+        for (int k = 0; k < 8; k++) nx[k] = make_float4(0, 0, 0, 0);
         if (wave_rows > 0 && wave_rows - 1 < nverts) {
             const float4* vx = gp.vtx.at(wave_rows - 1, pid);
-            n_pp = vx[VTX_P_PDF]; n_wi = vx[VTX_WI]; n_f0 = vx[VTX_F0]; n_f1 = vx[VTX_F1];
+            for (int k = 0; k < 8; k++) nx[k] = vx[k];
         }
         for (uint32_t v = wave_rows; v-- > 0;) {
             bool want = false;
-            const float4 pp = n_pp, wi = n_wi, f0 = n_f0, f1 = n_f1;
+            float4 cur[8];
+            for (int k = 0; k < 8; k++) cur[k] = nx[k];
             if (v > 0 && v - 1 < nverts) {
                 const float4* vn = gp.vtx.at(v - 1, pid);
-                n_pp = vn[VTX_P_PDF]; n_wi = vn[VTX_WI]; n_f0 = vn[VTX_F0]; n_f1 = vn[VTX_F1];
+                for (int k = 0; k < 8; k++) nx[k] = vn[k];
             }
+            const float4 pp = cur[VTX_P_PDF], wi = cur[VTX_WI];
             float radiance = 0.0f, u0 = 0.0f, u1 = 0.0f, u2 = 0.0f;
             if (v < nverts) {
-                const float4* vx = gp.vtx.at(v, pid);
                 radiance = spec_average(l) / pp.w;
                 want = isfinite(radiance) && radiance != 0.0f;  // STree::record's early return (stree.rs:102-116)
                 if (want) {
@@ -871,9 +874,9 @@ __global__ __launch_bounds__(kBlock) void k_guide_scan(SceneDev sc, RenderParams
                     u1 = rng_f32(rng);
                     u2 = rng_f32(rng);
                 }
-                l = l * spec_from(f0, f1);
-                if (f2u(wi.w) & 2u) l = l + spec_from(vx[VTX_LI0], vx[VTX_LI1]);
-                if (f2u(wi.w) & 1u) l = l + spec_from(vx[VTX_E0], vx[VTX_E1]);
+                l = l * spec_from(cur[VTX_F0], cur[VTX_F1]);
+                if (f2u(wi.w) & 2u) l = l + spec_from(cur[VTX_LI0], cur[VTX_LI1]);  // fields without their bit were never written
+                if (f2u(wi.w) & 1u) l = l + spec_from(cur[VTX_E0], cur[VTX_E1]);
             }
             const unsigned long long m = __ballot(want);
             if (m != 0ull) {
