@@ -75,6 +75,7 @@ INTEGRATOR_LIGHTPATH, INTEGRATOR_PATH, INTEGRATOR_GUIDED = 0, 1, 2
 MODE_PT, MODE_NEE, MODE_MIS = 0, 1, 2
 FILTER_NEAREST, FILTER_BOX, FILTER_STOCHASTIC = 0, 1, 2
 MAT_LAMBERTIAN, MAT_DIELECTRIC, MAT_CONDUCTOR = 0, 1, 2
+NOALLOC_MAX_RAYS = 1 << 18  # PTGPU_NOALLOC_MAX_RAYS
 
 # every symbol include/ptgpu.h declares (tests check the library exports all of them)
 PTGPU_SYMBOLS = [
@@ -82,6 +83,7 @@ PTGPU_SYMBOLS = [
     "ptgpu_render_shard", "ptgpu_guided_begin", "ptgpu_guided_wave", "ptgpu_guided_stats", "ptgpu_guided_end",
     "ptgpu_trace_batch", "ptgpu_occluded_batch", "ptgpu_scene_info", "ptgpu_scene_bvh", "ptgpu_set_profiling",
     "ptgpu_set_batch_paths", "ptgpu_kernel_times", "ptgpu_set_census", "ptgpu_census", "ptgpu_guided_selfcheck",
+    "ptgpu_trace_batch_noalloc",
 ]
 PTHOST_SYMBOLS = [
     "pthost_last_error", "pthost_scene_load", "pthost_scene_free", "pthost_scene_desc", "pthost_camera_desc",
@@ -143,6 +145,7 @@ def load_gpu() -> C.CDLL:
         lib.ptgpu_guided_end.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(Stats)]
         lib.ptgpu_guided_selfcheck.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64, C.POINTER(C.c_uint64)]
         lib.ptgpu_trace_batch.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_uint32, C.c_void_p]
+        lib.ptgpu_trace_batch_noalloc.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_uint32, C.c_void_p]
         lib.ptgpu_occluded_batch.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_uint32, C.POINTER(C.c_uint8)]
         lib.ptgpu_scene_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_float)]
         lib.ptgpu_scene_bvh.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
@@ -343,6 +346,13 @@ class Context:
         rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 7)
         out = np.zeros(rays.shape[0], dtype=HIT_DTYPE)
         self._check(self.lib.ptgpu_trace_batch(self.handle, _fptr(rays), rays.shape[0], out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def trace_noalloc(self, rays) -> np.ndarray:
+        """ptgpu_trace_batch_noalloc: same hits through the library's static scratch (no device allocation)."""
+        rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 7)
+        out = np.zeros(rays.shape[0], dtype=HIT_DTYPE)
+        self._check(self.lib.ptgpu_trace_batch_noalloc(self.handle, _fptr(rays), rays.shape[0], out.ctypes.data_as(C.c_void_p)))
         return out
 
     def occluded(self, p_from, p_to) -> np.ndarray:

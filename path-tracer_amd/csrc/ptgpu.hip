@@ -16,6 +16,15 @@
 
 using namespace pt;
 
+// Scratch of ptgpu_trace_batch_noalloc (include/ptgpu.h): the device-side staging of the rays and of the hit records that
+// ptgpu_trace_batch allocates per call. In host code this name is only a stand-in for the symbol: the device address
+// comes from hipGetSymbolAddress (ptgpu_init, once per context with its device current) and lives in ptgpu_ctx::scratch.
+// Every GPU the library runs on holds its own copy (15 MiB) until the process ends.
+constexpr uint32_t kNoAllocMaxRays = 1u << 18;
+constexpr size_t kNoAllocRayBytes = (size_t)kNoAllocMaxRays * 7 * sizeof(float);
+constexpr size_t kNoAllocHitBytes = (size_t)kNoAllocMaxRays * sizeof(ptgpu_hit);
+static __device__ __align__(256) unsigned char scratch[kNoAllocRayBytes + kNoAllocHitBytes];
+
 namespace {
 
 thread_local std::string g_err;
@@ -150,6 +159,7 @@ struct ptgpu_ctx {
     uint64_t launches = 0;
     GuidedState* guided = nullptr;
     GuidedPersist* guided_persist = nullptr;
+    unsigned char* scratch = nullptr;  // device address of `scratch` on this context's GPU (hipGetSymbolAddress)
 };
 
 namespace {
@@ -290,6 +300,7 @@ int ptgpu_init(ptgpu_ctx** out, int device_id) {
     (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
     hipError_t e = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_greatest);
     if (e == hipSuccess) e = hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_least);
+    if (e == hipSuccess) e = hipGetSymbolAddress((void**)&c->scratch, HIP_SYMBOL(scratch));  // this device's copy of the array
     if (e == hipSuccess) e = c->d_census.alloc(4);
     if (e == hipSuccess) e = hipMemset(c->d_census.p, 0, 4 * sizeof(unsigned long long));
     if (e == hipSuccess) e = c->d_d65.upload(std::vector<float>(kD65, kD65 + CIE_N), c->stream);
@@ -553,6 +564,26 @@ int ptgpu_trace_batch(ptgpu_ctx* c, const float* rays, uint32_t n, ptgpu_hit* hi
     HIP_TRY(hipMemcpyAsync(hits_out, d_hits.p, (size_t)n * sizeof(HitOut), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     resolve_stage_times(c);
+    return PTGPU_OK;
+}
+
+// ptgpu_trace_batch for callers that cannot allocate: same kernel, the staging buffers are the static scratch array.
+// No hipMalloc / hipFree / event creation here (hence no stage timer and no census).
+int ptgpu_trace_batch_noalloc(ptgpu_ctx* c, const float* rays, uint32_t n, ptgpu_hit* hits_out) {
+    if (!c || !c->have_scene) return fail(PTGPU_E_STATE, "trace_batch_noalloc: no scene");
+    if (n == 0) return PTGPU_OK;
+    if (!rays || !hits_out) return fail(PTGPU_E_INVALID, "trace_batch_noalloc: NULL buffer");
+    if (n > kNoAllocMaxRays) return fail(PTGPU_E_LIMIT, "trace_batch_noalloc: at most 262144 rays per call (the static scratch buffer's size)");
+    if (!c->scratch) return fail(PTGPU_E_DEVICE, "trace_batch_noalloc: scratch address unknown");
+    HIP_TRY(hipSetDevice(c->device));
+    float* d_rays = reinterpret_cast<float*>(c->scratch);
+    HitOut* d_hits = reinterpret_cast<HitOut*>(c->scratch + kNoAllocRayBytes);
+    // nothing in the scratch has to start at zero: the kernel writes every hit record in [0, n) and reads only rays [0, n)
+    HIP_TRY(hipMemcpyAsync(d_rays, rays, 7 * (size_t)n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_trace_batch<false>, dim3(grid_for(c, n)), dim3(kBlock), c->bvh_lds, c->stream, c->scene, d_rays, n, d_hits, (unsigned long long*)nullptr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(hits_out, d_hits, (size_t)n * sizeof(HitOut), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
     return PTGPU_OK;
 }
 
