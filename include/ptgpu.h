@@ -78,8 +78,10 @@ typedef struct ptgpu_integrator_desc {
     int32_t mode;                /* PTGPU_MODE_* (path, guided) */
     float spatial_threshold;     /* guided: `spatial_threashold` */
     float directional_threshold; /* guided: carried for fidelity; render uses 0.01 like path_guiding/mod.rs:73 */
-    int32_t spatial_filter;      /* guided: only STOCHASTIC (and NEAREST) supported = what the parser can select */
-    int32_t directional_filter;  /* guided: only BOX (and NEAREST) supported */
+    int32_t spatial_filter;      /* guided: must be STOCHASTIC, the only value the reference's parser selects (parser/mod.rs:144) */
+    int32_t directional_filter;  /* guided: must be BOX (parser/mod.rs:145); anything else fails with PTGPU_E_INVALID.
+                                  * Deviation: a directional quadtree is at most 24 levels deep here (cells of 2^-24; the
+                                  * reference has no cap, its u16 node links bound the node count only) */
 } ptgpu_integrator_desc;
 
 /* Counters filled by ptgpu_render*. Times are host wall-clock around the device work of the call. */
@@ -150,6 +152,38 @@ int ptgpu_guided_end(ptgpu_ctx* ctx, double* film_rgb_out, double* film_scale_ou
  * (STree::leaf, stree.rs:202-229)}: the last four must be 0. */
 int ptgpu_guided_selfcheck(ptgpu_ctx* ctx, uint32_t n_probes, uint64_t seed, uint64_t counts_out[5]);
 
+/* SD-tree parity hooks (no reference counterpart as an API), usable between two waves (after ptgpu_guided_wave returned).
+ * They expose the resident tree and run the production kernels' lookups, record pass and refinement on caller-supplied
+ * inputs, so that tests can hold the SAME tree on the GPU and in the CPU oracle and compare element-wise:
+ *   DTree::sample / DTree::pdf (path_guiding/dtree.rs:98-179), STree::leaf (stree.rs:202-229)       -> ptgpu_guided_probe
+ *   STree::record, stochastic filter (stree.rs:102-116,186-201) + DTree::record, box (dtree.rs:200-289) -> ptgpu_guided_record_batch
+ *   STree::new_iteration (stree.rs:42-101,255-260; dtree.rs:185-198,291-328)                       -> ptgpu_guided_refine
+ * "Resident tree" = the sampling tree the last traced wave drew from (iteration = that wave's index) and the collector
+ * it trained; after ptgpu_guided_refine, the tree the next wave will use and its empty collector. */
+typedef struct ptgpu_sdtree_info {
+    uint32_t n_spatial_nodes, n_leaves, n_sampling_nodes, n_collector_nodes;
+    uint32_t iteration;      /* Guider::iteration of the resident sampling tree */
+    uint32_t refined_ahead;  /* 1 after ptgpu_guided_refine until the next ptgpu_guided_wave */
+    float bounds[6];         /* STree::bounds (stree.rs:28-31): min.xyz, max.xyz */
+} ptgpu_sdtree_info;
+int ptgpu_guided_tree_info(ptgpu_ctx* ctx, ptgpu_sdtree_info* out);
+/* Any pointer may be NULL. spatial: 4 words per STree node {left, right, split_axis, leaf id | 0xffffffff for interior};
+ * leaf: 5 words per spatial leaf {first node in s_*, node count, first node in c_*, node count, sampler mean == 0};
+ * s_rad / c_rad: 4 floats per quadtree node (child sums), s_child / c_child: 4 u16 links (0 = leaf cell), node indices
+ * relative to the leaf's first node; s_weight / c_weight: statistical_weight of each leaf's sampler / collector DTree. */
+int ptgpu_guided_tree_download(ptgpu_ctx* ctx, uint32_t* spatial, uint32_t* leaf, float* s_rad, uint16_t* s_child, float* s_weight,
+                               float* c_rad, uint16_t* c_child, float* c_weight);
+/* Probe i: point = points[3i..], PCG stream = Sampler::init_pixel(i & 0xffff, i >> 16, seed); out_words[16i..] =
+ * {leaf id, sampled square x, y, tree pdf of it, tree pdf of query_sq[2i..], PCG state lo, hi after the draws,
+ *  1 if the shade kernel's split descent disagrees with the plain one, leaf box min.xyz max.xyz,
+ *  dir_to_square (mod.rs:412-421) of the point read as a direction: x, y} (floats as bits). */
+int ptgpu_guided_probe(ptgpu_ctx* ctx, const float* points, const float* query_sq, uint32_t n, uint64_t seed, uint32_t* out_words);
+/* Records n entries {p.xyz, wi.xyz, radiance, u0, u1, u2} (u*: the stochastic filter's three jitter draws) into the
+ * resident collector through the production record pass (k_guide_locate/scatter/splat_bins, k_push_lazy, k_fold_weights). */
+int ptgpu_guided_record_batch(ptgpu_ctx* ctx, const float* records, uint32_t n);
+/* Builds the tree of the next wave now (what the next ptgpu_guided_wave would do first); that call then skips it. */
+int ptgpu_guided_refine(ptgpu_ctx* ctx);
+
 /* Parity hooks (no reference counterpart as an API; they expose Scene::intersect_t -> Bvh::intersect,
  * pt/src/bvh.rs:86-142, and Scene::occluded, pt/src/scene.rs:229-235, on caller-supplied rays).
  * rays: n * 7 floats (ox,oy,oz, dx,dy,dz, t_max).
@@ -184,6 +218,12 @@ int ptgpu_kernel_times(ptgpu_ctx* ctx, double* ms_out, uint64_t* launches_out, u
  * out[0..3] = BVH nodes visited / triangles tested by extend rays, then by occlusion rays, since it was enabled. */
 int ptgpu_set_census(ptgpu_ctx* ctx, int enabled);
 int ptgpu_census(ptgpu_ctx* ctx, uint64_t out[4]);
+/* Deviations that are safety limits, counted since ptgpu_init whenever one actually cut something short (tests assert 0):
+ * out[0] = paths ended after 256 consecutive crossings of material-less surfaces (the reference would never return from
+ * such a sample, path_tracer.rs:76-80), out[1] = guided path vertices dropped for lack of a vertex-store row (rows =
+ * max_depth + 1, one per bounce plus the miss vertex: cannot happen), out[2] = quadtree cells the refinement declined to
+ * split because they sit at level 24 (the reference has no depth cap, dtree.rs:291-324). */
+int ptgpu_guard_counts(ptgpu_ctx* ctx, uint64_t out[3]);
 /* Paths kept in flight per batch (state SoA size); 0 restores the default. */
 int ptgpu_set_batch_paths(ptgpu_ctx* ctx, uint32_t n_paths);
 

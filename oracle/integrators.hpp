@@ -427,50 +427,57 @@ struct GuidedReport {
     size_t stree_nodes = 0, stree_leaves = 0, dtree_nodes_total = 0;
 };
 
-// PathGuidingIntegrator::render (mod.rs:70-122). Sharding hook: only the sample passes with
-// (pass % sample_step == sample_begin) are run (used to rehearse multi-GPU statistics sums on the CPU).
+// The sample passes [first_index, first_index + wave_size) of one wave (mod.rs:84-118): every pass visits every pixel
+// once, tile-parallel, records each path back to front into the collectors and adds it to the film.
+inline void guided_wave_passes(const Scene& scene, const Camera& cam, const IntegratorDesc& it, Guider& guider, Film& film, size_t first_index,
+                               size_t wave_size, int n_threads, RayStats* st) {
+    auto tiles = create_tiles(film.w, film.h);
+    for (size_t k = 0; k < wave_size; k++) {
+        size_t i = first_index + k;
+        parallel_tiles(tiles, n_threads, [&](const Tile& tile, size_t) {
+            std::vector<PathVertex> path;
+            Sampler sampler;
+            for (size_t oy = 0; oy < tile.size[1]; oy++)
+                for (size_t ox = 0; ox < tile.size[0]; ox++) {
+                    size_t ix = tile.min[0] + ox, iy = tile.min[1] + oy;
+                    SWL swl = SWL::sample_visible(sampler.wavelength_sample());  // BEFORE init_pixel (mod.rs:92-94)
+                    sampler.init_pixel(ix, iy, i);
+                    float u[2];
+                    sampler.sample2d(u);
+                    Ray ray = cam.sample_we(ix, iy, u);
+                    path.clear();
+                    guided_random_walk(scene, it, ray, swl, path, guider, sampler, st);
+                    SSpec l = SSpec::zero();
+                    for (size_t vi = path.size(); vi-- > 0;) {
+                        const PathVertex& v = path[vi];
+                        if (!v.is_specular) {
+                            float r = l.average() / v.wi_pdf;
+                            guider.stree.record(v.p, v.wi, r, sampler);
+                        }
+                        l = l * v.f;
+                        l = l + v.li;
+                        l = l + v.emitted;
+                    }
+                    film_add_pixel(film, ix, iy, l, swl);
+                }
+        });
+    }
+}
+
+// PathGuidingIntegrator::render (mod.rs:70-122).
 inline void guided_render(const Scene& scene, const Camera& cam, const IntegratorDesc& it, size_t spp, Film& film, int n_threads,
                           RayStats* st, GuidedReport* rep, size_t max_waves = ~size_t(0)) {
     Guider guider;
     guider.stree.init(scene.bounds(), it.spatial_filter, it.directional_filter);
     guider.directional_threshold = 0.01f;  // hard-coded (mod.rs:73)
     guider.spatial_threshold = it.spatial_threshold;
-    auto tiles = create_tiles(film.w, film.h);
     size_t wave_index = 0, waves_done = 0;
     for (size_t wave_size : wave_sample_counts(spp)) {
         if (waves_done++ >= max_waves) break;
         film.clear();
         guider.new_iteration();
-        for (size_t k = 0; k < wave_size; k++) {
-            size_t i = wave_index++;
-            parallel_tiles(tiles, n_threads, [&](const Tile& tile, size_t) {
-                std::vector<PathVertex> path;
-                Sampler sampler;
-                for (size_t oy = 0; oy < tile.size[1]; oy++)
-                    for (size_t ox = 0; ox < tile.size[0]; ox++) {
-                        size_t ix = tile.min[0] + ox, iy = tile.min[1] + oy;
-                        SWL swl = SWL::sample_visible(sampler.wavelength_sample());  // BEFORE init_pixel (mod.rs:92-94)
-                        sampler.init_pixel(ix, iy, i);
-                        float u[2];
-                        sampler.sample2d(u);
-                        Ray ray = cam.sample_we(ix, iy, u);
-                        path.clear();
-                        guided_random_walk(scene, it, ray, swl, path, guider, sampler, st);
-                        SSpec l = SSpec::zero();
-                        for (size_t vi = path.size(); vi-- > 0;) {
-                            const PathVertex& v = path[vi];
-                            if (!v.is_specular) {
-                                float r = l.average() / v.wi_pdf;
-                                const_cast<Guider&>(guider).stree.record(v.p, v.wi, r, sampler);
-                            }
-                            l = l * v.f;
-                            l = l + v.li;
-                            l = l + v.emitted;
-                        }
-                        film_add_pixel(film, ix, iy, l, swl);
-                    }
-            });
-        }
+        guided_wave_passes(scene, cam, it, guider, film, wave_index, wave_size, n_threads, st);
+        wave_index += wave_size;
     }
     if (rep) {
         rep->stree_nodes = guider.stree.nodes.size();

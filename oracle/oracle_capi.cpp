@@ -285,3 +285,216 @@ int orc_dtree_exercise(const float* pts2, const float* rad, uint32_t n, int filt
 }
 
 }  // extern "C"
+
+// ---- SD-tree handle: the same tree on both sides (tests/test_gpu_sdtree.py). Layout of the flat arrays = ptgpu_guided_tree_download.
+struct orc_sdtree {
+    Guider guider;
+    std::vector<uint32_t> leaf_id;  // per spatial node (0xffffffff for interior), numbered in node order like the product's host tree
+    void renumber() {
+        leaf_id.assign(guider.stree.nodes.size(), 0xffffffffu);
+        uint32_t next = 0;
+        for (size_t i = 0; i < guider.stree.nodes.size(); i++)
+            if (guider.stree.nodes[i].is_leaf()) leaf_id[i] = next++;
+    }
+};
+
+// A DTree from `n` flat nodes (4 sums + 4 u16 links each, links relative to the tree's first node).
+static DTree dtree_from_flat(const float* rad, const uint16_t* child, uint32_t n, float weight, Filter f) {
+    DTree d;
+    d.filter = f;
+    d.statistical_weight = weight;
+    d.nodes.resize(n);
+    for (uint32_t k = 0; k < n; k++)
+        for (int c = 0; c < 4; c++) {
+            d.nodes[k].radiance[c] = rad[4 * (size_t)k + c];
+            d.nodes[k].children[c] = child[4 * (size_t)k + c];
+        }
+    return d;
+}
+// Reachable nodes in a canonical order (preorder by an explicit stack, children numbered as discovered), so that two
+// trees of equal shape compare equal whatever their internal numbering / free slots. Returns the deepest level.
+static uint32_t dtree_canonical(const DTree& d, std::vector<float>& rad, std::vector<uint16_t>& child) {
+    struct It { uint16_t old_i; uint32_t new_i, depth; };
+    const size_t base = rad.size() / 4;
+    std::vector<It> stack{{0, 0, 1}};
+    uint32_t counter = 1, deepest = 1;
+    rad.resize(4 * (base + 1));
+    child.resize(4 * (base + 1), 0);
+    while (!stack.empty()) {
+        const It it = stack.back();
+        stack.pop_back();
+        deepest = std::max(deepest, it.depth);
+        const DTreeNode& n = d.nodes[it.old_i];
+        for (int c = 0; c < 4; c++) {
+            rad[4 * (base + it.new_i) + c] = n.radiance[c];
+            if (n.is_leaf(c)) continue;
+            const uint32_t id = counter++;
+            rad.resize(4 * (base + counter));
+            child.resize(4 * (base + counter), 0);
+            child[4 * (base + it.new_i) + c] = (uint16_t)id;
+            stack.push_back({n.children[c], id, it.depth + 1});
+        }
+    }
+    return deepest;
+}
+
+extern "C" {
+
+orc_sdtree* orc_sdtree_fresh(orc_scene* s, float spatial_threshold) {  // Guider::new (mod.rs:71-77)
+    if (!s) return nullptr;
+    orc_sdtree* t = new orc_sdtree();
+    t->guider.stree.init(s->scene.bounds(), Filter::Stochastic, Filter::Box);
+    t->guider.directional_threshold = 0.01f;
+    t->guider.spatial_threshold = spatial_threshold;
+    t->renumber();
+    return t;
+}
+orc_sdtree* orc_sdtree_create(const float* bounds6, const uint32_t* spatial, uint32_t n_spatial, const uint32_t* leaf, uint32_t n_leaves, const float* s_rad,
+                              const uint16_t* s_child, const float* s_weight, const float* c_rad, const uint16_t* c_child, const float* c_weight,
+                              float spatial_threshold) {
+    orc_sdtree* t = new orc_sdtree();
+    STree& st = t->guider.stree;
+    st.bounds = B3{v3(bounds6[0], bounds6[1], bounds6[2]), v3(bounds6[3], bounds6[4], bounds6[5])};
+    st.filter = Filter::Stochastic;
+    st.nodes.resize(n_spatial);
+    for (uint32_t i = 0; i < n_spatial; i++) {
+        STreeNode& n = st.nodes[i];
+        n.left = spatial[4 * i];
+        n.right = spatial[4 * i + 1];
+        n.split_axis = spatial[4 * i + 2];
+        if (n.left != 0) {
+            if (n.left >= n_spatial || n.right >= n_spatial || n.left <= i || n.right <= i) { delete t; return nullptr; }
+            st.nodes[n.left].depth = st.nodes[n.right].depth = n.depth + 1;  // children come after their parent
+            n.sampler = DTree::no_alloc();
+            n.collector = DTree::no_alloc();
+            continue;
+        }
+        const uint32_t l = spatial[4 * i + 3];
+        if (l >= n_leaves) { delete t; return nullptr; }
+        const uint32_t* li = leaf + 5 * (size_t)l;
+        n.sampler = dtree_from_flat(s_rad + 4 * (size_t)li[0], s_child + 4 * (size_t)li[0], li[1], s_weight[l], Filter::Box);
+        n.collector = dtree_from_flat(c_rad + 4 * (size_t)li[2], c_child + 4 * (size_t)li[2], li[3], c_weight[l], Filter::Box);
+    }
+    t->guider.directional_threshold = 0.01f;
+    t->guider.spatial_threshold = spatial_threshold;
+    t->guider.has_started = true;
+    t->renumber();
+    return t;
+}
+void orc_sdtree_destroy(orc_sdtree* t) { delete t; }
+
+// out[5] = spatial nodes, leaves, reachable sampling nodes, reachable collector nodes, deepest quadtree level (root = 1)
+void orc_sdtree_sizes(orc_sdtree* t, uint32_t* out) {
+    std::vector<float> r;
+    std::vector<uint16_t> c;
+    uint32_t leaves = 0, ns = 0, nc = 0, deepest = 0;
+    for (const STreeNode& n : t->guider.stree.nodes) {
+        if (!n.is_leaf()) continue;
+        leaves++;
+        r.clear(); c.clear();
+        deepest = std::max(deepest, dtree_canonical(n.sampler, r, c));
+        ns += (uint32_t)(r.size() / 4);
+        r.clear(); c.clear();
+        deepest = std::max(deepest, dtree_canonical(n.collector, r, c));
+        nc += (uint32_t)(r.size() / 4);
+    }
+    out[0] = (uint32_t)t->guider.stree.nodes.size();
+    out[1] = leaves; out[2] = ns; out[3] = nc; out[4] = deepest;
+}
+// The tree in the flat layout, quadtrees in canonical numbering (arrays sized from orc_sdtree_sizes).
+void orc_sdtree_export(orc_sdtree* t, float* bounds6, uint32_t* spatial, uint32_t* leaf, float* s_rad, uint16_t* s_child, float* s_weight, float* c_rad,
+                       uint16_t* c_child, float* c_weight) {
+    const STree& st = t->guider.stree;
+    bounds6[0] = st.bounds.min.x; bounds6[1] = st.bounds.min.y; bounds6[2] = st.bounds.min.z;
+    bounds6[3] = st.bounds.max.x; bounds6[4] = st.bounds.max.y; bounds6[5] = st.bounds.max.z;
+    std::vector<float> sr, cr;
+    std::vector<uint16_t> sc, cc;
+    for (size_t i = 0; i < st.nodes.size(); i++) {
+        const STreeNode& n = st.nodes[i];
+        spatial[4 * i] = (uint32_t)n.left; spatial[4 * i + 1] = (uint32_t)n.right; spatial[4 * i + 2] = (uint32_t)n.split_axis;
+        spatial[4 * i + 3] = t->leaf_id[i];
+        if (!n.is_leaf()) continue;
+        const uint32_t l = t->leaf_id[i];
+        const uint32_t s0 = (uint32_t)(sr.size() / 4), c0 = (uint32_t)(cr.size() / 4);
+        dtree_canonical(n.sampler, sr, sc);
+        dtree_canonical(n.collector, cr, cc);
+        leaf[5 * (size_t)l] = s0; leaf[5 * (size_t)l + 1] = (uint32_t)(sr.size() / 4) - s0;
+        leaf[5 * (size_t)l + 2] = c0; leaf[5 * (size_t)l + 3] = (uint32_t)(cr.size() / 4) - c0;
+        leaf[5 * (size_t)l + 4] = n.sampler.mean() == 0.0f ? 1u : 0u;
+        s_weight[l] = n.sampler.statistical_weight;
+        c_weight[l] = n.collector.statistical_weight;
+    }
+    std::memcpy(s_rad, sr.data(), sr.size() * 4); std::memcpy(s_child, sc.data(), sc.size() * 2);
+    std::memcpy(c_rad, cr.data(), cr.size() * 4); std::memcpy(c_child, cc.data(), cc.size() * 2);
+}
+// Same 16 words per probe as ptgpu_guided_probe: STree::leaf, DTree::sample, DTree::pdf (twice).
+void orc_sdtree_probe(orc_sdtree* t, const float* points, const float* query_sq, uint32_t n, uint64_t seed, uint32_t* out) {
+    const STree& st = t->guider.stree;
+    for (uint32_t i = 0; i < n; i++) {
+        const V3 p = v3(points[3 * (size_t)i], points[3 * (size_t)i + 1], points[3 * (size_t)i + 2]);
+        B3 lb;
+        const size_t ni = st.leaf(p, &lb);
+        const DTree& d = st.nodes[ni].sampler;
+        Sampler smp;
+        smp.init_pixel(i & 0xffffu, i >> 16, (size_t)seed);
+        const V2 sq = d.sample(smp);
+        const float pdf_s = d.pdf(sq), pdf_q = d.pdf(V2{query_sq[2 * (size_t)i], query_sq[2 * (size_t)i + 1]});
+        uint32_t* o = out + 16 * (size_t)i;
+        const float f[5] = {sq.x, sq.y, pdf_s, pdf_q, 0.0f};
+        o[0] = t->leaf_id[ni];
+        std::memcpy(o + 1, f, 16);
+        o[5] = (uint32_t)smp.pcg.state; o[6] = (uint32_t)(smp.pcg.state >> 32); o[7] = 0;
+        const float b[6] = {lb.min.x, lb.min.y, lb.min.z, lb.max.x, lb.max.y, lb.max.z};
+        std::memcpy(o + 8, b, 24);
+        const V2 dsq = dir_to_square(p);
+        std::memcpy(o + 14, &dsq.x, 4);
+        std::memcpy(o + 15, &dsq.y, 4);
+    }
+}
+// records: n * 10 floats {p, wi, radiance, u0, u1, u2}: STree::record with the stochastic filter's draws replayed.
+void orc_sdtree_record(orc_sdtree* t, const float* records, uint32_t n) {
+    Sampler unused;
+    for (uint32_t i = 0; i < n; i++) {
+        const float* r = records + 10 * (size_t)i;
+        t->guider.stree.record_drawn(v3(r[0], r[1], r[2]), v3(r[3], r[4], r[5]), r[6], r[7], r[8], r[9], unused);
+    }
+}
+void orc_sdtree_new_iteration(orc_sdtree* t, uint32_t iteration) {  // Guider::new_iteration's refinement (mod.rs:372-383)
+    t->guider.stree.new_iteration(t->guider.directional_threshold, t->guider.spatial_threshold, iteration);
+    t->renumber();
+}
+// One wave of PathGuidingIntegrator::render on this tree: passes [first_pass, first_pass + n_passes) with Guider::iteration
+// = `iteration`; the film holds this wave only (film.clear(), mod.rs:80). stats_out[4]: samples, extend, shadow, segments.
+int orc_guided_wave(orc_scene* s, orc_sdtree* t, const ptgpu_camera_desc* cam, const ptgpu_integrator_desc* integ, uint32_t iteration, uint64_t first_pass,
+                    uint32_t n_passes, int n_threads, double* film_out, uint64_t* stats_out) {
+    if (!s || !t || !cam || !integ) return -1;
+    if (n_threads <= 0) n_threads = (int)std::thread::hardware_concurrency();
+    if (n_threads <= 0) n_threads = 1;
+    Camera camera;
+    camera.init(cam->world_to_camera, cam->fov_deg, cam->resx, cam->resy);
+    IntegratorDesc it;
+    it.kind = IntegratorKind::Guided;
+    it.max_depth = integ->max_depth;
+    it.mode = (Mode)integ->mode;
+    it.spatial_threshold = integ->spatial_threshold;
+    it.directional_threshold = integ->directional_threshold;
+    it.spatial_filter = Filter::Stochastic;
+    it.directional_filter = Filter::Box;
+    Film film;
+    film.init(cam->resx, cam->resy);
+    RayStats st;
+    t->guider.iteration = iteration;
+    t->guider.has_started = true;
+    guided_wave_passes(s->scene, camera, it, t->guider, film, (size_t)first_pass, n_passes, n_threads, &st);
+    if (film_out)
+        for (size_t i = 0; i < film.pixels.size(); i++) film_out[i] = film.pixels[i] + film.splats[i];
+    if (stats_out) {
+        stats_out[0] = (uint64_t)n_passes * cam->resx * cam->resy;
+        stats_out[1] = st.extend_rays.load();
+        stats_out[2] = st.shadow_rays.load();
+        stats_out[3] = st.segments.load();
+    }
+    return 0;
+}
+
+}  // extern "C"

@@ -343,12 +343,22 @@ struct STree {
         record_box_recursive(bounds, footprint, p2, radiance, 0, sampler);
     }
     void record_stochastic(V3 p3, V2 p2, float radiance, Sampler& sampler) {  // stree.rs:186-201
+        float u0 = sampler.sample1d(), u1 = sampler.sample1d(), u2 = sampler.sample1d();
+        record_stochastic_drawn(p3, p2, radiance, u0, u1, u2, sampler);
+    }
+    // the body of record_stochastic after its three draws (split off so that a test can replay given draws)
+    void record_stochastic_drawn(V3 p3, V2 p2, float radiance, float u0, float u1, float u2, Sampler& sampler) {
         B3 lb;
         leaf(p3, &lb);
         B3 jitter = B3::around(p3, lb.extent());
-        float u0 = sampler.sample1d(), u1 = sampler.sample1d(), u2 = sampler.sample1d();
         V3 q = bounds.clip(jitter.lerp(v3(u0, u1, u2)));
         record_nearest(q, p2, radiance, sampler);
+    }
+    // STree::record (stree.rs:102-116) with the stochastic filter's draws supplied by the caller
+    void record_drawn(V3 p, V3 wi, float radiance, float u0, float u1, float u2, Sampler& sampler) {
+        if (!std::isfinite(radiance)) return;
+        if (radiance == 0.0f) return;
+        record_stochastic_drawn(p, dir_to_square(wi), radiance, u0, u1, u2, sampler);
     }
     void record(V3 p, V3 wi, float radiance, Sampler& sampler) {  // stree.rs:102-116
         if (!std::isfinite(radiance)) return;

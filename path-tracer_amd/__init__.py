@@ -63,6 +63,11 @@ class Stats(C.Structure):
         return {k: getattr(self, k) for k, _ in self._fields_}
 
 
+class SdTreeInfo(C.Structure):
+    _fields_ = [("n_spatial_nodes", C.c_uint32), ("n_leaves", C.c_uint32), ("n_sampling_nodes", C.c_uint32), ("n_collector_nodes", C.c_uint32),
+                ("iteration", C.c_uint32), ("refined_ahead", C.c_uint32), ("bounds", C.c_float * 6)]
+
+
 class Hit(C.Structure):
     _fields_ = [("mesh_index", C.c_uint32), ("triangle_index", C.c_uint32), ("leaf_index", C.c_uint32), ("hit", C.c_uint32),
                 ("t", C.c_float), ("b0", C.c_float), ("b1", C.c_float), ("b2", C.c_float)]
@@ -83,7 +88,8 @@ PTGPU_SYMBOLS = [
     "ptgpu_render_shard", "ptgpu_guided_begin", "ptgpu_guided_wave", "ptgpu_guided_stats", "ptgpu_guided_end",
     "ptgpu_trace_batch", "ptgpu_occluded_batch", "ptgpu_scene_info", "ptgpu_scene_bvh", "ptgpu_set_profiling",
     "ptgpu_set_batch_paths", "ptgpu_kernel_times", "ptgpu_set_census", "ptgpu_census", "ptgpu_guided_selfcheck",
-    "ptgpu_trace_batch_noalloc",
+    "ptgpu_trace_batch_noalloc", "ptgpu_guided_tree_info", "ptgpu_guided_tree_download", "ptgpu_guided_probe",
+    "ptgpu_guided_record_batch", "ptgpu_guided_refine", "ptgpu_guard_counts",
 ]
 PTHOST_SYMBOLS = [
     "pthost_last_error", "pthost_scene_load", "pthost_scene_free", "pthost_scene_desc", "pthost_camera_desc",
@@ -144,6 +150,11 @@ def load_gpu() -> C.CDLL:
         lib.ptgpu_guided_stats.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
         lib.ptgpu_guided_end.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(Stats)]
         lib.ptgpu_guided_selfcheck.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64, C.POINTER(C.c_uint64)]
+        lib.ptgpu_guided_tree_info.argtypes = [C.c_void_p, C.POINTER(SdTreeInfo)]
+        lib.ptgpu_guided_tree_download.argtypes = [C.c_void_p] + [C.c_void_p] * 8
+        lib.ptgpu_guided_probe.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_uint32, C.c_uint64, C.c_void_p]
+        lib.ptgpu_guided_record_batch.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_uint32]
+        lib.ptgpu_guided_refine.argtypes = [C.c_void_p]
         lib.ptgpu_trace_batch.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_uint32, C.c_void_p]
         lib.ptgpu_trace_batch_noalloc.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_uint32, C.c_void_p]
         lib.ptgpu_occluded_batch.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_uint32, C.POINTER(C.c_uint8)]
@@ -153,6 +164,7 @@ def load_gpu() -> C.CDLL:
         lib.ptgpu_set_batch_paths.argtypes = [C.c_void_p, C.c_uint32]
         lib.ptgpu_set_census.argtypes = [C.c_void_p, C.c_int]
         lib.ptgpu_census.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+        lib.ptgpu_guard_counts.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
         lib.ptgpu_kernel_times.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_uint32]
         _gpu = lib
     return _gpu
@@ -322,6 +334,12 @@ class Context:
         self._check(self.lib.ptgpu_census(self.handle, out))
         return {"extend_nodes": out[0], "extend_tris": out[1], "occlude_nodes": out[2], "occlude_tris": out[3]}
 
+    def guard_counts(self):
+        """How often a documented safety limit cut something short since the context was created (ptgpu_guard_counts)."""
+        out = (C.c_uint64 * 3)()
+        self._check(self.lib.ptgpu_guard_counts(self.handle, out))
+        return {"pass_through": out[0], "vertex_store": out[1], "quad_level": out[2]}
+
     def kernel_times(self):
         """{stage: (total_ms, launches)} of the last render with profiling on."""
         ms = (C.c_double * len(KERNEL_NAMES))()
@@ -417,6 +435,37 @@ class Context:
         out = (C.c_uint64 * 5)()
         self._check(self.lib.ptgpu_guided_selfcheck(self.handle, C.c_uint32(n_probes), C.c_uint64(seed), out))
         return tuple(int(v) for v in out)
+
+    # SD-tree parity hooks
+    def guided_tree(self):
+        """The resident SD-tree as a dict of numpy arrays (layout: ptgpu_guided_tree_download in include/ptgpu.h)."""
+        info = SdTreeInfo()
+        self._check(self.lib.ptgpu_guided_tree_info(self.handle, C.byref(info)))
+        t = {"iteration": info.iteration, "bounds": np.array(list(info.bounds), dtype=np.float32),
+             "spatial": np.zeros((info.n_spatial_nodes, 4), dtype=np.uint32), "leaf": np.zeros((info.n_leaves, 5), dtype=np.uint32),
+             "s_rad": np.zeros((info.n_sampling_nodes, 4), dtype=np.float32), "s_child": np.zeros((info.n_sampling_nodes, 4), dtype=np.uint16),
+             "s_weight": np.zeros(info.n_leaves, dtype=np.float32),
+             "c_rad": np.zeros((info.n_collector_nodes, 4), dtype=np.float32), "c_child": np.zeros((info.n_collector_nodes, 4), dtype=np.uint16),
+             "c_weight": np.zeros(info.n_leaves, dtype=np.float32)}
+        ptrs = [t[k].ctypes.data_as(C.c_void_p) for k in ("spatial", "leaf", "s_rad", "s_child", "s_weight", "c_rad", "c_child", "c_weight")]
+        self._check(self.lib.ptgpu_guided_tree_download(self.handle, *ptrs))
+        return t
+
+    def guided_probe(self, points, query_sq, seed=1) -> np.ndarray:
+        """-> (n, 16) uint32 words per probe (see ptgpu_guided_probe)."""
+        pts = np.ascontiguousarray(points, dtype=np.float32).reshape(-1, 3)
+        q = np.ascontiguousarray(query_sq, dtype=np.float32).reshape(-1, 2)
+        assert len(pts) == len(q)
+        out = np.zeros((len(pts), 16), dtype=np.uint32)
+        self._check(self.lib.ptgpu_guided_probe(self.handle, _fptr(pts), _fptr(q), len(pts), C.c_uint64(seed), out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def guided_record_batch(self, records):
+        rec = np.ascontiguousarray(records, dtype=np.float32).reshape(-1, 10)
+        self._check(self.lib.ptgpu_guided_record_batch(self.handle, _fptr(rec), len(rec)))
+
+    def guided_refine(self):
+        self._check(self.lib.ptgpu_guided_refine(self.handle))
 
     def guided_end(self):
         film = np.zeros((self.cam.resy, self.cam.resx, 3), dtype=np.float64)

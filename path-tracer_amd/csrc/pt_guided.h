@@ -639,7 +639,8 @@ __global__ __launch_bounds__(kBlock, KINDS != 7 ? PT_GUIDED_DIFFUSE_WAVES : PT_S
                     store_vertex_light(gp, nverts, pid, spec_splat(0.0f), spec_splat(0.0f), false, false);
                     store_vertex(gp, nverts, pid, o + d * 10000.0f, d, 1.0f, spec_splat(1.0f), false, false);
                     nverts++;
-                }
+                } else
+                    atomicAdd(sc.guards + kGuardVertexStore, 1u);
                 ended = true;
             } else {
                 const float4 tb = hit.tb[i];
@@ -652,6 +653,7 @@ __global__ __launch_bounds__(kBlock, KINDS != 7 ? PT_GUIDED_DIFFUSE_WAVES : PT_S
                     // pass-through: no bounce counted and, unlike `path`, specular_bounce is left alone (mod.rs:153-156)
                     o = offset_ray_origin(sf.blo, sf.bhi, sf.ng, d);
                     alive = passthrough_step(flags);
+                    if (!alive) atomicAdd(sc.guards + kGuardPassThrough, 1u);
                     ended = !alive;
                 } else {
                     shaded = true;
@@ -749,8 +751,10 @@ __global__ __launch_bounds__(kBlock, KINDS != 7 ? PT_GUIDED_DIFFUSE_WAVES : PT_S
                             shadow_row = nverts;
                             want_shadow = has_nee;
                             nverts++;
-                        } else
+                        } else {
                             skipped_shadow = has_nee;
+                            if (!specular) atomicAdd(sc.guards + kGuardVertexStore, 1u);
+                        }
                         beta = beta * fw;
                         if (spec_is_black(beta)) ended = true;
                         else {
@@ -963,12 +967,48 @@ __global__ __launch_bounds__(kBlock) void k_guided_selfcheck(SdTreeDev tree, uin
     if (f2u(pdf_c) != f2u(pdf_d) || rc.state != rng.state) atomicAdd(counts + 3, 1ull);
 }
 
-// c_weight[l] += the private counts of leaf l (whole numbers: the order of the sum does not matter).
+// Parity hook (ptgpu_guided_probe): what the shade kernel's lookups return for caller-supplied points, for comparison with
+// the CPU oracle's STree::leaf / DTree::sample / DTree::pdf on the same tree. Per probe 16 words:
+//   [0] spatial leaf id  [1..2] sampled square point  [3] tree pdf of that point  [4] tree pdf of the query point
+//   [5..6] PCG state after the sampling draws  [7] 1 if the shade kernel's split descent (stree_code + stree_resolve)
+//   disagrees with stree_leaf  [8..13] the leaf's box (lo, hi)  [14..15] dir_to_square of the point read as a direction
+//   (the one libm call, atan2f, on the record path: tests use it to tell last-ulp libm differences from real ones)
+__global__ __launch_bounds__(kBlock) void k_guided_probe(SdTreeDev tree, const float* points, const float* query, uint32_t n_probes, uint64_t seed, uint32_t* out) {
+    __shared__ float sm_scales[(kMaxQuadLevel + 1) * kBlock];
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_probes) return;
+    const V3 p = mk3(points[3 * (size_t)i], points[3 * (size_t)i + 1], points[3 * (size_t)i + 2]);
+    V3 lo, hi;
+    uint32_t word = 0;
+    const uint32_t leaf_id = stree_leaf<true>(tree, p, lo, hi, &word);
+    const uint32_t word2 = stree_resolve(tree, tree.top[stree_code(tree, p)], p);
+    const uint4 leaf = make_uint4(word & 0x7fffffffu, 0u, word >> 31, 0u);
+    float* scales = sm_scales + threadIdx.x;
+    Rng rng = rng_init_pixel(i & 0xffffu, i >> 16, seed);
+    V2 sq = V2{0.0f, 0.0f};
+    const SNode root = tree.s_node[leaf.x];
+    const float pdf_s = dtree_walk(tree, leaf, true, rng, sq, scales, root);
+    V2 q = V2{query[2 * (size_t)i], query[2 * (size_t)i + 1]};
+    Rng unused = rng;
+    const float pdf_q = dtree_walk(tree, leaf, false, unused, q, scales, root);
+    uint32_t* o = out + 16 * (size_t)i;
+    o[0] = leaf_id; o[1] = f2u(sq.x); o[2] = f2u(sq.y); o[3] = f2u(pdf_s); o[4] = f2u(pdf_q);
+    o[5] = (uint32_t)rng.state; o[6] = (uint32_t)(rng.state >> 32); o[7] = word2 != word ? 1u : 0u;
+    o[8] = f2u(lo.x); o[9] = f2u(lo.y); o[10] = f2u(lo.z); o[11] = f2u(hi.x); o[12] = f2u(hi.y); o[13] = f2u(hi.z);
+    const V2 dsq = dir_to_square(p);
+    o[14] = f2u(dsq.x); o[15] = f2u(dsq.y);
+}
+
+// c_weight[l] += the private counts of leaf l (whole numbers: the order of the sum does not matter); the private copies
+// are left at zero, so folding twice (ptgpu_guided_record_batch after a wave) counts nothing twice.
 __global__ __launch_bounds__(kBlock) void k_fold_weights(SdTreeDev tree) {
     const uint32_t l = blockIdx.x * blockDim.x + threadIdx.x;
     if (l >= tree.n_leaves) return;
     float w = tree.c_weight[l];
-    for (uint32_t k = 0; k < kWeightCopies; k++) w += tree.w_private[(size_t)k * tree.n_leaves + l];
+    for (uint32_t k = 0; k < kWeightCopies; k++) {
+        w += tree.w_private[(size_t)k * tree.n_leaves + l];
+        tree.w_private[(size_t)k * tree.n_leaves + l] = 0.0f;
+    }
     tree.c_weight[l] = w;
 }
 

@@ -337,6 +337,7 @@ __global__ __launch_bounds__(kBlock, KINDS != 7 ? PT_PATH_DIFFUSE_WAVES : PT_SHA
                     o = offset_ray_origin(sf.blo, sf.bhi, sf.ng, d);
                     flags |= FLAG_SPECULAR_BOUNCE;
                     alive = passthrough_step(flags);
+                    if (!alive) atomicAdd(sc.guards + kGuardPassThrough, 1u);
                     do_film = !alive;
                 } else {
                     shaded = true;

@@ -30,8 +30,9 @@ struct RefineArgs {
     uint32_t* new_size;         // per new leaf: node count of the reshaped collector
     const uint32_t* new_off;    // per new leaf: first node (exclusive scan of new_size)
     uint2* new_child;           // reshaped collector topology
-    uint4* leaf_info;           // per new leaf: {s_off, new_off, sampler mean == 0, -}
+    uint4* leaf_info;           // per new leaf: {s_off, new_off, sampler mean == 0, bits of the sampler's statistical weight}
     uint32_t* error_flag;       // set when a quadtree would need more than 65535 nodes
+    uint32_t* guards;           // SceneDev::guards
     float threshold;            // directional threshold (0.01, mod.rs:73)
 };
 
@@ -95,7 +96,10 @@ PT_D uint32_t reshape_collector(const RefineArgs& a, uint32_t old_base, uint32_t
                 for (uint32_t k = 0; k < it.depth; k++) frac *= 0.25f;  // 0.25f32.powi(depth), exact
             }
             if (frac < a.threshold) continue;  // stays (or becomes) a leaf cell
-            if (it.depth >= kMaxQuadLevel) continue;  // a node there would be out of every walk's reach (they stop at kMaxQuadLevel)
+            if (it.depth >= kMaxQuadLevel) {  // a node there would be out of every walk's reach (they stop at kMaxQuadLevel)
+                if (!WRITE) atomicAdd(a.guards + kGuardQuadLevel, 1u);
+                continue;
+            }
             if (counter >= 65535u) {
                 *a.error_flag = 1u;
                 continue;
@@ -127,7 +131,7 @@ __global__ __launch_bounds__(kBlock) void k_refine_emit_count(RefineArgs a) {
     // DTree::mean() == 0 (dtree.rs:71-77) decides between uniform and tree sampling
     const float mean = weight == 0.0f ? 0.0f : sum4(a.old_rad[ob]) / (kFourPi * weight);
     a.new_size[leaf] = reshape_collector<false>(a, ob, 0u);
-    a.leaf_info[leaf] = make_uint4(sb, 0u, mean == 0.0f ? 1u : 0u, 0u);
+    a.leaf_info[leaf] = make_uint4(sb, 0u, mean == 0.0f ? 1u : 0u, f2u(weight));  // w: the sampling copy's statistical weight (parity hooks)
 }
 
 __global__ __launch_bounds__(kBlock) void k_refine_write(RefineArgs a) {

@@ -63,7 +63,13 @@ struct SceneDev {
     uint32_t lds_nodes;                // != 0: the kernels copy the node array (n_nodes * 32 B, small scenes) into LDS behind the stacks (bvh_stage_nodes)
     uint32_t bvh_stack;                // LDS stack entries per ray = tree depth + 1 (kernels get 256 * bvh_stack * 4 B of dynamic LDS)
     V3 bounds_lo, bounds_hi;
+    uint32_t* guards;                  // kGuard* counters: how often a documented safety limit cut something short (ptgpu_guard_counts)
 };
+// Limits the reference does not have; each is counted when it actually changes a result, so tests can assert "never".
+enum { kGuardPassThrough = 0,   // a path ended after kMaxPassThrough consecutive pass-through crossings (pt_state.h)
+       kGuardVertexStore = 1,   // a guided path vertex beyond the vertex store's rows was dropped (cannot happen: rows = max_depth + 1)
+       kGuardQuadLevel = 2,     // the refinement declined to split a quadtree cell at level kMaxQuadLevel (pt_guided.h)
+       kNumGuards = 3 };
 
 struct CameraDev {
     Mat4 c2w, w2c;

@@ -154,6 +154,7 @@ struct ptgpu_ctx {
     std::map<const void*, int> resident_blocks;  // per shade kernel: workgroups resident per CU (resident_grid)
     size_t bvh_lds = 0;  // dynamic LDS bytes of every kernel that walks the BVH (pt_device.h: bvh_intersect)
     DevBuf<unsigned long long> d_census;  // extend nodes, extend tris, occlude nodes, occlude tris
+    DevBuf<uint32_t> d_guards;            // kGuard* counters (pt_types.h), cumulative since ptgpu_init
     double stage_ms[PTGPU_N_STAGES] = {0, 0, 0, 0, 0, 0};
     uint64_t stage_launches[PTGPU_N_STAGES] = {0, 0, 0, 0, 0, 0};
     uint64_t launches = 0;
@@ -303,6 +304,8 @@ int ptgpu_init(ptgpu_ctx** out, int device_id) {
     if (e == hipSuccess) e = hipGetSymbolAddress((void**)&c->scratch, HIP_SYMBOL(scratch));  // this device's copy of the array
     if (e == hipSuccess) e = c->d_census.alloc(4);
     if (e == hipSuccess) e = hipMemset(c->d_census.p, 0, 4 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = c->d_guards.alloc(kNumGuards);
+    if (e == hipSuccess) e = hipMemset(c->d_guards.p, 0, kNumGuards * sizeof(uint32_t));
     if (e == hipSuccess) e = c->d_d65.upload(std::vector<float>(kD65, kD65 + CIE_N), c->stream);
     if (e == hipSuccess) e = c->d_xyz.upload(std::vector<double>(&kXyz[0][0], &kXyz[0][0] + 3 * CIE_N), c->stream);
     if (e != hipSuccess) {
@@ -465,6 +468,7 @@ int ptgpu_scene_create(ptgpu_ctx* c, const ptgpu_scene_desc* desc) {
     s.emissive_tris = c->d_emissive.p;
     s.d65 = c->d_d65.p;
     s.cie_xyz = c->d_xyz.p;
+    s.guards = c->d_guards.p;
     s.n_nodes = (uint32_t)n_nodes;
     s.n_tris = (uint32_t)n_tris;
     s.n_emissive_tris = (uint32_t)emissive_ids.size();
@@ -633,6 +637,15 @@ int ptgpu_census(ptgpu_ctx* c, uint64_t out[4]) {
     unsigned long long h[4];
     HIP_TRY(hipMemcpy(h, c->d_census.p, sizeof(h), hipMemcpyDeviceToHost));
     for (int i = 0; i < 4; i++) out[i] = h[i];
+    return PTGPU_OK;
+}
+int ptgpu_guard_counts(ptgpu_ctx* c, uint64_t out[3]) {
+    if (!c || !out) return fail(PTGPU_E_INVALID, "guard_counts: NULL argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    uint32_t h[kNumGuards];
+    HIP_TRY(hipMemcpy(h, c->d_guards.p, sizeof(h), hipMemcpyDeviceToHost));
+    for (int i = 0; i < kNumGuards; i++) out[i] = h[i];
     return PTGPU_OK;
 }
 int ptgpu_set_batch_paths(ptgpu_ctx* c, uint32_t n_paths) {

@@ -34,6 +34,18 @@ def load():
         lib.orc_fresnel.argtypes = [C.c_float, C.c_float]
         lib.orc_complex_fresnel.restype = C.c_float
         lib.orc_complex_fresnel.argtypes = [C.c_float, C.c_float, C.c_float]
+        lib.orc_sdtree_fresh.restype = C.c_void_p
+        lib.orc_sdtree_fresh.argtypes = [C.c_void_p, C.c_float]
+        lib.orc_sdtree_create.restype = C.c_void_p
+        lib.orc_sdtree_create.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32] + [C.c_void_p] * 6 + [C.c_float]
+        lib.orc_sdtree_destroy.argtypes = [C.c_void_p]
+        lib.orc_sdtree_sizes.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
+        lib.orc_sdtree_export.argtypes = [C.c_void_p] * 10
+        lib.orc_sdtree_probe.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_uint32, C.c_uint64, C.c_void_p]
+        lib.orc_sdtree_record.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_uint32]
+        lib.orc_sdtree_new_iteration.argtypes = [C.c_void_p, C.c_uint32]
+        lib.orc_guided_wave.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(pt.CameraDesc), C.POINTER(pt.IntegratorDesc), C.c_uint32, C.c_uint64, C.c_uint32,
+                                        C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
         _lib = lib
     return _lib
 
@@ -101,6 +113,90 @@ class OracleScene:
             raise RuntimeError("orc_render failed")
         keys = ["samples", "extend_rays", "shadow_rays", "segments", "nodes", "tris", "stree_nodes", "dtree_nodes"]
         return film, scale.value, dict(zip(keys, list(st)))
+
+
+TREE_KEYS = ("spatial", "leaf", "s_rad", "s_child", "s_weight", "c_rad", "c_child", "c_weight")
+
+
+class OracleSdTree:
+    """The oracle's Guider/STree behind a handle; flat arrays in the layout of ptgpu_guided_tree_download, so that the same
+    tree can be held on the GPU and here (tests/test_gpu_sdtree.py)."""
+
+    def __init__(self, handle):
+        if not handle:
+            raise RuntimeError("orc_sdtree: inconsistent tree description")
+        self.lib = load()
+        self.handle = handle
+
+    @classmethod
+    def fresh(cls, oscene: "OracleScene", spatial_threshold: float):
+        return cls(load().orc_sdtree_fresh(oscene.handle, spatial_threshold))
+
+    @classmethod
+    def from_arrays(cls, t: dict, spatial_threshold: float):
+        a = {k: np.ascontiguousarray(t[k]) for k in TREE_KEYS}
+        b = np.ascontiguousarray(t["bounds"], dtype=np.float32)
+        assert a["spatial"].dtype == np.uint32 and a["leaf"].dtype == np.uint32 and a["s_child"].dtype == np.uint16 and a["c_child"].dtype == np.uint16
+        vp = lambda x: x.ctypes.data_as(C.c_void_p)  # noqa: E731
+        return cls(load().orc_sdtree_create(vp(b), vp(a["spatial"]), len(a["spatial"]), vp(a["leaf"]), len(a["leaf"]), vp(a["s_rad"]), vp(a["s_child"]),
+                                            vp(a["s_weight"]), vp(a["c_rad"]), vp(a["c_child"]), vp(a["c_weight"]), spatial_threshold))
+
+    def close(self):
+        if self.handle:
+            self.lib.orc_sdtree_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def export(self) -> dict:
+        """Canonical form: quadtree nodes renumbered in a fixed traversal order, unreachable (freed) nodes dropped."""
+        sz = (C.c_uint32 * 5)()
+        self.lib.orc_sdtree_sizes(self.handle, sz)
+        t = {"bounds": np.zeros(6, dtype=np.float32), "spatial": np.zeros((sz[0], 4), dtype=np.uint32), "leaf": np.zeros((sz[1], 5), dtype=np.uint32),
+             "s_rad": np.zeros((sz[2], 4), dtype=np.float32), "s_child": np.zeros((sz[2], 4), dtype=np.uint16), "s_weight": np.zeros(sz[1], dtype=np.float32),
+             "c_rad": np.zeros((sz[3], 4), dtype=np.float32), "c_child": np.zeros((sz[3], 4), dtype=np.uint16), "c_weight": np.zeros(sz[1], dtype=np.float32),
+             "deepest_level": int(sz[4])}
+        self.lib.orc_sdtree_export(self.handle, *[t[k].ctypes.data_as(C.c_void_p) for k in ("bounds",) + TREE_KEYS])
+        return t
+
+    def probe(self, points, query_sq, seed=1) -> np.ndarray:
+        pts = np.ascontiguousarray(points, dtype=np.float32).reshape(-1, 3)
+        q = np.ascontiguousarray(query_sq, dtype=np.float32).reshape(-1, 2)
+        out = np.zeros((len(pts), 16), dtype=np.uint32)
+        self.lib.orc_sdtree_probe(self.handle, fptr(pts), fptr(q), len(pts), C.c_uint64(seed), out.ctypes.data_as(C.c_void_p))
+        return out
+
+    def record(self, records):
+        rec = np.ascontiguousarray(records, dtype=np.float32).reshape(-1, 10)
+        self.lib.orc_sdtree_record(self.handle, fptr(rec), len(rec))
+
+    def new_iteration(self, iteration: int):
+        self.lib.orc_sdtree_new_iteration(self.handle, iteration)
+
+    def wave(self, oscene: "OracleScene", cam, integrator, iteration, first_pass, n_passes, n_threads=0):
+        """-> (film sums of this wave (H,W,3), stats dict)"""
+        cam = pt.CameraDesc.from_buffer_copy(cam)
+        integ = pt.IntegratorDesc.from_buffer_copy(integrator)
+        film = np.zeros((cam.resy, cam.resx, 3), dtype=np.float64)
+        st = (C.c_uint64 * 4)()
+        rc = self.lib.orc_guided_wave(oscene.handle, self.handle, C.byref(cam), C.byref(integ), iteration, C.c_uint64(first_pass), n_passes, n_threads,
+                                      film.ctypes.data_as(C.POINTER(C.c_double)), st)
+        if rc != 0:
+            raise RuntimeError("orc_guided_wave failed")
+        return film, dict(zip(["samples", "extend_rays", "shadow_rays", "segments"], list(st)))
+
+
+def canonical(t: dict, spatial_threshold: float = 1000.0) -> dict:
+    """Canonical form of a flat tree (e.g. a GPU download): through the oracle's importer and exporter."""
+    h = OracleSdTree.from_arrays(t, spatial_threshold)
+    try:
+        return h.export()
+    finally:
+        h.close()
 
 
 def rel_mse(img, ref):

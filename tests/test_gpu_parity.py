@@ -307,9 +307,11 @@ def test_guided_furnace_matches_the_reference_energy_loss(gpu_ctx):
 
 @pytest.mark.parametrize("name,res,spp,depth", [("cornell-box-guided", (64, 64), 63, 8), ("veach-bidir", (64, 64), 31, 8)])
 def test_guided_image_and_tree_match_oracle(gpu_ctx, name, res, spp, depth):
-    """Same scene, spp and RNG streams. Atomic splat order differs (f32), and one flipped decision changes what a leaf
-    learns, so trees and images agree statistically: image means within 2 %, block-averaged relMSE small, SD-tree
-    sizes within 15 %."""
+    """Two FREE-RUNNING renders (the lock-step comparison, which is deterministic, is tests/test_gpu_sdtree.py): same
+    scene, spp and RNG streams, but the f32 atomic order of the GPU's splats differs from the oracle's, a near-tie in
+    `frac < 0.01` then splits a quadtree cell on one side only, and from there the two sides draw different samples.
+    Measured on MI355X (tools/dbg_free_running.py): spatial trees equal (333/333, 151/151 nodes), directional nodes within
+    4 of 13 149, image means within 1e-3, block relMSE <= 1.2e-4. Bounds below = those with a margin of ~10x."""
     sc = pt.LoadedScene(name, resx=res[0], resy=res[1], max_depth=depth, integrator="guided")
     o = ob.OracleScene(sc)
     gpu_ctx.load(sc)
@@ -322,12 +324,12 @@ def test_guided_image_and_tree_match_oracle(gpu_ctx, name, res, spp, depth):
     k = 8
     gb = g.reshape(res[1] // k, k, res[0] // k, k, 3).mean(axis=(1, 3))
     cb = c.reshape(res[1] // k, k, res[0] // k, k, 3).mean(axis=(1, 3))
-    assert cst["stree_nodes"] > 3
-    assert abs(gst["stree_nodes"] - cst["stree_nodes"]) <= 0.15 * cst["stree_nodes"] + 2, (gst["stree_nodes"], cst["stree_nodes"])
-    assert abs(gst["dtree_nodes"] - cst["dtree_nodes"]) <= 0.15 * cst["dtree_nodes"] + 8, (gst["dtree_nodes"], cst["dtree_nodes"])
-    assert abs(np.median(gb) / np.median(cb) - 1.0) < 0.05
-    assert abs(gst["extend_rays"] / cst["extend_rays"] - 1.0) < 0.02
-    assert ob.rel_mse(np.minimum(gb, 5.0), np.minimum(cb, 5.0)) < 0.05
+    assert cst["stree_nodes"] > 100
+    assert abs(gst["stree_nodes"] - cst["stree_nodes"]) <= 0.01 * cst["stree_nodes"] + 2, (gst["stree_nodes"], cst["stree_nodes"])
+    assert abs(gst["dtree_nodes"] - cst["dtree_nodes"]) <= 0.01 * cst["dtree_nodes"] + 8, (gst["dtree_nodes"], cst["dtree_nodes"])
+    assert abs(g.mean() / c.mean() - 1.0) < 0.01
+    assert abs(gst["extend_rays"] / cst["extend_rays"] - 1.0) < 2e-3
+    assert ob.rel_mse(np.minimum(gb, 5.0), np.minimum(cb, 5.0)) < 2e-3
 
 
 def test_guided_wave_api_and_stats_buffer(gpu_ctx):

@@ -1,0 +1,245 @@
+"""Deterministic SD-tree parity (needs an MI355X): the GPU and the CPU oracle hold the SAME tree and are compared
+element by element, instead of comparing two free-running renders statistically.
+
+  (i)   DTree::sample / DTree::pdf (dtree.rs:98-179) and STree::leaf (stree.rs:202-229): the resident tree is downloaded,
+        loaded into the oracle, and probed on both sides — sampled point, PCG state after the draws, both pdfs, leaf id and
+        leaf box must agree bit for bit (no libm on that path).
+  (ii)  STree::record with the stochastic filter (stree.rs:102-116,186-201) + DTree::record with the box filter
+        (dtree.rs:200-289): one fixed batch of records, with the filter's jitter draws given, goes through the production
+        record pass and through the oracle; statistical weights must agree exactly, collector sums to f32 summation order.
+  (iii) STree::new_iteration (stree.rs:42-101,255-260; dtree.rs:185-198,291-328): both sides refine from identical sums;
+        spatial nodes, quadtree topology, sampling sums and weights must be equal.
+  (iv)  A whole guided render in lock step: every wave is traced on both sides from the same sampling tree (the oracle's
+        collector is re-synchronised to the GPU's statistics before each refinement, so f32 atomic order cannot
+        accumulate into different trees); per wave the collectors, and at the end the image, are compared like the
+        `path` integrator's: path for path up to last-ulp libm flips.
+Everything goes through the C ABI (parity hooks of include/ptgpu.h)."""
+import numpy as np
+import pytest
+
+import oracle_bind as ob
+import path_tracer_amd as pt
+import scenes_util as su
+
+pytestmark = pytest.mark.gpu
+
+TOPOLOGY_KEYS = ("spatial", "s_child", "c_child")
+
+
+def waves_of(spp):
+    lib = ob.load()
+    import ctypes as C
+    n = C.c_uint32()
+    buf = (C.c_uint32 * 64)()
+    lib.orc_wave_sample_counts(spp, C.byref(n), buf, 64)
+    return [int(buf[i]) for i in range(n.value)]
+
+
+def surface_points(o, rng, n):
+    info = o.info()
+    rays = su.random_rays(rng, 2 * n, info["bounds"][:3], info["bounds"][3:])
+    h = o.trace(rays)
+    idx = np.nonzero(h["hit"])[0][:n]
+    return (rays[idx, :3] + rays[idx, 3:6] * h["t"][idx, None]).astype(np.float32)
+
+
+def assert_same_tree(a, b, sums=True):
+    """Two canonical exports: same spatial tree, same quadtree shapes, (optionally) same numbers, bit for bit."""
+    for k in TOPOLOGY_KEYS:
+        assert a[k].shape == b[k].shape, (k, a[k].shape, b[k].shape)
+        assert (a[k] == b[k]).all(), k
+    assert (a["leaf"] == b["leaf"]).all()
+    assert (a["bounds"].view(np.uint32) == b["bounds"].view(np.uint32)).all()
+    if sums:
+        for k in ("s_rad", "s_weight", "c_rad", "c_weight"):
+            assert (a[k].view(np.uint32) == b[k].view(np.uint32)).all(), k
+
+
+def probe_inputs(o, t, rng, n):
+    lo, hi = t["bounds"][:3], t["bounds"][3:]
+    ext = hi - lo
+    pts = np.concatenate([
+        surface_points(o, rng, n // 2),                                              # where the leaves are deep
+        rng.uniform(lo, hi, (n // 4, 3)).astype(np.float32),
+        rng.uniform(lo - 0.1 * ext, hi + 0.1 * ext, (n // 4, 3)).astype(np.float32),  # STree::leaf never bounds-checks
+    ])
+    q = rng.random((len(pts), 2)).astype(np.float32)
+    q[:64] = rng.choice(np.array([0.0, 0.25, 0.5, 0.75, 1.0], dtype=np.float32), (64, 2))  # cell boundaries
+    return pts, q
+
+
+@pytest.mark.parametrize("name,res,spp,depth,thr", [("cornell-box-guided", (96, 96), 127, 8, 100.0), ("veach-bidir", (64, 64), 63, 16, 100.0)])
+def test_sdtree_lookups_and_refinement_match_oracle_on_the_same_tree(gpu_ctx, name, res, spp, depth, thr):
+    """(i) and (iii) on the trees of a real render, after waves 1, 3 and 5."""
+    sc = pt.LoadedScene(name, resx=res[0], resy=res[1], max_depth=depth, integrator="guided")
+    o = ob.OracleScene(sc)
+    gpu_ctx.load(sc)
+    integ = pt.IntegratorDesc.from_buffer_copy(sc.integrator)
+    integ.spatial_threshold = thr
+    guards_before = gpu_ctx.guard_counts()
+    n_waves = gpu_ctx.guided_begin(integ, spp)
+    rng = np.random.default_rng(17)
+    checked = 0
+    for w in range(n_waves):
+        gpu_ctx.guided_wave(w)
+        if w not in (1, 3, 5) or w + 1 == n_waves:
+            continue
+        t = gpu_ctx.guided_tree()
+        assert t["iteration"] == w
+        O = ob.OracleSdTree.from_arrays(t, thr)
+        e = O.export()
+        assert e["deepest_level"] < 24                      # the quadtree depth cap (a deviation) is nowhere near
+        assert (e["leaf"][:, 4] == t["leaf"][:, 4]).all()    # "sampler mean == 0" flag = DTree::mean() == 0 of the oracle
+        # (i) probes
+        pts, q = probe_inputs(o, t, rng, 100000)
+        g, c = gpu_ctx.guided_probe(pts, q, seed=w), O.probe(pts, q, seed=w)
+        assert (g[:, 7] == 0).all()                          # the shade kernel's split descent finds the same leaf
+        assert (t["leaf"][g[:, 0], 4] == 0).mean() > 0.5     # most probes sample a trained distribution
+        for col, what in ((0, "leaf id"), (1, "sample x"), (2, "sample y"), (3, "pdf(sample)"), (4, "pdf(query)"), (5, "rng lo"), (6, "rng hi")):
+            assert (g[:, col] == c[:, col]).all(), (w, what, int((g[:, col] != c[:, col]).sum()))
+        assert (g[:, 8:14] == c[:, 8:14]).all()              # leaf box bits
+        # (iii) refinement from identical sums
+        gpu_ctx.guided_refine()
+        t2 = gpu_ctx.guided_tree()
+        assert t2["iteration"] == w + 1
+        O.new_iteration(w)
+        want, got = O.export(), ob.canonical(t2, thr)
+        assert len(want["spatial"]) >= len(e["spatial"]) and len(want["c_rad"]) > 1
+        assert_same_tree(got, want)
+        assert not got["c_rad"].any() and not got["c_weight"].any()   # subdivide_and_clear
+        O.close()
+        checked += 1
+    gpu_ctx.guided_end()
+    assert checked >= 2
+    assert gpu_ctx.guard_counts() == guards_before   # no documented safety limit was hit
+
+
+@pytest.mark.parametrize("direct", [False, True])
+def test_sdtree_record_batch_matches_oracle(gpu_ctx, direct, monkeypatch):
+    """(ii), then (iii) on the statistics the batch left. `direct` = the per-record splat (PTGPU_DIRECT_SPLAT) instead of
+    the binned pass: both are checked against the oracle, not against each other."""
+    if direct:
+        monkeypatch.setenv("PTGPU_DIRECT_SPLAT", "1")
+    thr = 100.0
+    sc = pt.LoadedScene("cornell-box-guided", resx=96, resy=96, max_depth=8)
+    o = ob.OracleScene(sc)
+    gpu_ctx.load(sc)
+    integ = pt.IntegratorDesc.from_buffer_copy(sc.integrator)
+    integ.spatial_threshold = thr
+    n_waves = gpu_ctx.guided_begin(integ, 31)
+    rng = np.random.default_rng(23)
+    for w in range(4):
+        gpu_ctx.guided_wave(w)
+    t0 = gpu_ctx.guided_tree()
+    assert len(t0["leaf"]) > 8 and len(t0["c_rad"]) > 500
+    # an empty collector of the live shape on both sides
+    _, count = gpu_ctx.guided_stats()
+    gpu_ctx.guided_stats_set(np.zeros(count, dtype=np.float32))
+    t0["c_rad"][:] = 0
+    t0["c_weight"][:] = 0
+    O = ob.OracleSdTree.from_arrays(t0, thr)
+    n = 150000
+    p = surface_points(o, rng, n)
+    wi = rng.normal(size=(len(p), 3)).astype(np.float32)
+    wi /= np.linalg.norm(wi, axis=1, keepdims=True).astype(np.float32)
+    wi[:8] = np.array([[0, 0, 1], [0, 0, -1], [1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [1, 1e-8, 0], [1, -1e-8, 0]], dtype=np.float32)  # poles, seam
+    # dir_to_square is the one libm call on the record path (atan2f): device and host results differ in the last place
+    # for some directions, which moves that record's footprint by 2^-24 and changes sliver overlaps by a visible
+    # fraction. Keep the directions on which both libms agree, so that what is left to compare is summation order.
+    zero2 = np.zeros((len(wi), 2), dtype=np.float32)
+    sq_g, sq_c = gpu_ctx.guided_probe(wi, zero2)[:, 14:16], O.probe(wi, zero2)[:, 14:16]
+    same = (sq_g == sq_c).all(axis=1)
+    assert same.mean() > 0.7 and np.abs(sq_g.view(np.float32) - sq_c.view(np.float32)).max() < 3e-7, same.mean()
+    p, wi = p[same], wi[same]
+    rad = np.exp(rng.normal(size=len(p))).astype(np.float32)
+    u = rng.random((len(p), 3)).astype(np.float32)
+    rec = np.concatenate([p, wi, rad[:, None], u], axis=1).astype(np.float32)
+    gpu_ctx.guided_record_batch(rec)
+    O.record(rec)
+    t1 = gpu_ctx.guided_tree()
+    got, want = ob.canonical(t1, thr), O.export()
+    assert_same_tree(got, want, sums=False)
+    assert (got["c_weight"] == want["c_weight"]).all() and want["c_weight"].sum() == len(rec)   # every record found the oracle's leaf
+    a, b = got["c_rad"].astype(np.float64), want["c_rad"].astype(np.float64)
+    assert abs(a.sum() / b.sum() - 1.0) < 1e-6
+    touched = b > 0
+    assert touched.mean() > 0.3
+    rel = np.abs(a - b)[touched] / b[touched]
+    # same terms, another order of f32 additions: a cell that received k terms is off by ~sqrt(k) * 2^-24
+    assert rel.max() < 1e-5, rel.max()
+    assert not a[~touched].any()
+    # radiance the host refuses (STree::record returns early on these; k_guide_scan never queues them)
+    bad = rec[:1].copy()
+    for v in (0.0, np.inf, np.nan):
+        bad[0, 6] = v
+        with pytest.raises(pt.PtError):
+            gpu_ctx.guided_record_batch(bad)
+    # (iii) from the batch's statistics
+    gpu_ctx.guided_refine()
+    O2 = ob.OracleSdTree.from_arrays(t1, thr)
+    O2.new_iteration(t1["iteration"])
+    assert_same_tree(ob.canonical(gpu_ctx.guided_tree(), thr), O2.export())
+    for w in range(4, n_waves):
+        gpu_ctx.guided_wave(w)          # the render goes on from the hook-built tree
+    film, scale, st = gpu_ctx.guided_end()
+    assert np.isfinite(film).all() and st["samples"] == 96 * 96 * 31
+
+
+@pytest.mark.parametrize("name,res,spp,depth,thr", [
+    ("cornell-box-guided", (64, 64), 63, 8, 200.0),
+    ("veach-bidir", (64, 64), 31, 32, 200.0),     # BASELINE configs[4] at reduced size: deep specular chains, smooth normals
+    ("veach-mis", (80, 48), 31, 32, 200.0),       # configs[4], the scene with the most triangles: GGX conductors, 61 440 emitters
+])
+def test_guided_render_in_lock_step_with_oracle(gpu_ctx, name, res, spp, depth, thr):
+    """(iv): wave by wave from the same sampling tree; the image of the last wave pixel by pixel."""
+    sc = pt.LoadedScene(name, resx=res[0], resy=res[1], max_depth=depth, integrator="guided")
+    o = ob.OracleScene(sc)
+    gpu_ctx.load(sc)
+    integ = pt.IntegratorDesc.from_buffer_copy(sc.integrator)
+    integ.spatial_threshold = thr
+    waves = waves_of(spp)
+    guards_before = gpu_ctx.guard_counts()
+    assert gpu_ctx.guided_begin(integ, spp) == len(waves)
+    O = ob.OracleSdTree.fresh(o, thr)
+    first = 0
+    film_o = None
+    rays = [0, 0, 0, 0]
+    for w, n_passes in enumerate(waves):
+        gpu_ctx.guided_wave(w)
+        t = gpu_ctx.guided_tree()
+        film_o, st_o = O.wave(o, sc.camera, integ, w, first, n_passes)
+        first += n_passes
+        for i, k in enumerate(("extend_rays", "shadow_rays", "segments", "samples")):
+            rays[i] += st_o[k]
+        got, want = ob.canonical(t, thr), O.export()
+        assert_same_tree(got, want, sums=False)                                   # same sampling tree, same collector shape
+        assert (got["s_rad"].view(np.uint32) == want["s_rad"].view(np.uint32)).all()
+        # the collectors the wave trained: same records up to the few paths a last-ulp libm difference re-routes
+        gw, ww = got["c_weight"].astype(np.float64), want["c_weight"].astype(np.float64)
+        # (one re-routed path adds or removes up to depth + 1 records; measured: veach-bidir at depth 32 re-routes ~1 path in 4 000)
+        assert abs(gw.sum() - ww.sum()) <= 2e-3 * ww.sum() + depth + 1, (w, gw.sum(), ww.sum())
+        assert (np.abs(gw - ww) <= 5e-3 * ww + depth + 1).all(), (w, np.abs(gw - ww).max())
+        off = np.concatenate([want["leaf"][:, 2], [len(want["c_rad"])]])
+        per_leaf = lambda x: np.add.reduceat(x["c_rad"].astype(np.float64).sum(axis=1), off[:-1])  # noqa: E731
+        ga, wa = per_leaf(got), per_leaf(want)
+        assert abs(ga.sum() / wa.sum() - 1.0) < 2e-3, (w, ga.sum(), wa.sum())
+        # both refine from the GPU's statistics
+        O.close()
+        O = ob.OracleSdTree.from_arrays(t, thr)
+        if w + 1 < len(waves):
+            gpu_ctx.guided_refine()
+            O.new_iteration(w)
+            assert_same_tree(ob.canonical(gpu_ctx.guided_tree(), thr), O.export())
+    gf, gs, gst = gpu_ctx.guided_end()
+    assert gs == 1.0 / waves[-1]
+    g, c = gf * gs, film_o * gs
+    rel = np.abs(g - c).sum(axis=2) / (np.abs(c).sum(axis=2) + 1e-6)
+    assert np.median(rel) < 1e-5, np.median(rel)
+    assert (rel < 1e-3).mean() > 0.98, (rel < 1e-3).mean()
+    assert abs(g.mean() / c.mean() - 1.0) < 2e-3, (g.mean(), c.mean())
+    assert ob.rel_mse(g, c) < 1e-3
+    for i, k in enumerate(("extend_rays", "shadow_rays", "segments", "samples")):
+        assert abs(gst[k] - rays[i]) <= 2e-4 * rays[i] + 4, (k, gst[k], rays[i])
+    assert len(want["spatial"]) > 3 and want["deepest_level"] < 24
+    # the limits the reference does not have (256 pass-through crossings, vertex-store rows, quadtree level 24) were never hit
+    assert gpu_ctx.guard_counts() == guards_before

@@ -380,3 +380,45 @@ def test_glass_cube_transform_order():
     P = np.ctypeslib.as_array(cube.points, shape=(cube.n_points, 3))
     assert np.allclose(P[:, 1].min(), 0.5) and np.allclose(P[:, 1].max(), 1.5)
     assert np.allclose(np.abs(P[:, [0, 2]]).max(), 0.5 * 2 ** 0.5, atol=1e-6)
+
+
+# ------------------------------------------------------------------ SD-tree handle (the checker of tests/test_gpu_sdtree.py)
+def test_oracle_sdtree_handle_waves_equal_whole_render_and_roundtrip():
+    """Tracing wave by wave on an orc_sdtree handle is PathGuidingIntegrator::render cut at its wave boundaries: same tree
+    sizes and image as the one-call render; export -> import -> export is the identity and both copies answer probes alike."""
+    import oracle_bind as ob
+    sc = pt.LoadedScene("cornell-box-guided", resx=32, resy=32, max_depth=6)
+    o = ob.OracleScene(sc)
+    integ = pt.IntegratorDesc.from_buffer_copy(sc.integrator)
+    integ.spatial_threshold = 100.0
+    T = ob.OracleSdTree.fresh(o, 100.0)
+    first, film = 0, None
+    for w, n in enumerate([1, 2, 4, 8]):
+        if w > 0:
+            T.new_iteration(w - 1)
+        film, _ = T.wave(o, sc.camera, integ, w, first, n, n_threads=1)
+        first += n
+    whole, scale, st = o.render(sc.camera, integ, 15, n_threads=1)
+    e = T.export()
+    assert len(e["spatial"]) == st["stree_nodes"] > 3 and len(e["s_rad"]) == st["dtree_nodes"]
+    assert np.array_equal(film, whole) and scale == 1.0 / 8.0    # single-threaded: the same additions in the same order
+    T2 = ob.OracleSdTree.from_arrays(e, 100.0)
+    e2 = T2.export()
+    for k in ob.TREE_KEYS:
+        assert np.array_equal(e[k], e2[k]), k
+    rng = np.random.default_rng(0)
+    pts = rng.uniform(e["bounds"][:3], e["bounds"][3:], (2000, 3)).astype(np.float32)
+    q = rng.random((2000, 2)).astype(np.float32)
+    a, b = T.probe(pts, q, 3), T2.probe(pts, q, 3)
+    assert np.array_equal(a, b)
+    assert (e["leaf"][a[:, 0], 4] == 0).mean() > 0.5       # trained leaves
+    # records with replayed draws: weights count them, sums add up
+    rec = np.concatenate([pts[:500], np.tile([0, 0, 1], (500, 1)), np.ones((500, 1)), rng.random((500, 3))], axis=1).astype(np.float32)
+    rec[0, 6] = 0.0
+    rec[1, 6] = np.inf
+    before = T.export()
+    T.record(rec)
+    after = T.export()
+    assert after["c_weight"].sum() - before["c_weight"].sum() == 498
+    leaf_cells = after["c_child"] == 0
+    assert abs((after["c_rad"][leaf_cells].sum() - before["c_rad"][leaf_cells].sum()) - 498.0) < 0.05
