@@ -222,8 +222,9 @@ int ptgpu_census(ptgpu_ctx* ctx, uint64_t out[4]);
  * out[0] = paths ended after 256 consecutive crossings of material-less surfaces (the reference would never return from
  * such a sample, path_tracer.rs:76-80), out[1] = guided path vertices dropped for lack of a vertex-store row (rows =
  * max_depth + 1, one per bounce plus the miss vertex: cannot happen), out[2] = quadtree cells the refinement declined to
- * split because they sit at level 24 (the reference has no depth cap, dtree.rs:291-324). */
-int ptgpu_guard_counts(ptgpu_ctx* ctx, uint64_t out[3]);
+ * split because they sit at level 24 (the reference has no depth cap, dtree.rs:291-324), out[3] = samples dropped
+ * because their radiance was not finite (the reference asserts, path_tracer.rs:46, or poisons the pixel). */
+int ptgpu_guard_counts(ptgpu_ctx* ctx, uint64_t out[4]);
 /* Paths kept in flight per batch (state SoA size); 0 restores the default. */
 int ptgpu_set_batch_paths(ptgpu_ctx* ctx, uint32_t n_paths);
 

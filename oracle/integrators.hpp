@@ -66,9 +66,21 @@ inline void parallel_tiles(const std::vector<Tile>& tiles, int n_threads, F f) {
     for (auto& t : th) t.join();
 }
 
+// Samples that are not finite are dropped and counted on both sides (the reference asserts on them in `path`,
+// path_tracer.rs:46, and would poison the pixel in the other integrators): see pt_kernels.h, film_add_rgb_wave.
+inline std::atomic<uint64_t>& nonfinite_samples() {
+    static std::atomic<uint64_t> n{0};
+    return n;
+}
+inline bool rgb_finite_or_count(const double rgb[3]) {
+    if (std::isfinite(rgb[0]) && std::isfinite(rgb[1]) && std::isfinite(rgb[2])) return true;
+    nonfinite_samples()++;
+    return false;
+}
 inline void film_add_pixel(Film& film, size_t ix, size_t iy, const SSpec& l, const SWL& swl) {  // camera.rs:138-140
     double rgb[3];
     spectrum_to_rgb(l, swl, rgb);
+    if (!rgb_finite_or_count(rgb)) return;
     double* p = &film.pixels[3 * (ix + iy * film.w)];
     p[0] += rgb[0];
     p[1] += rgb[1];
@@ -83,6 +95,7 @@ inline void film_add_splat(Film& film, SplatLocks& locks, V2 p_raster, const SSp
     size_t idx = ix + iy * film.w;
     double rgb[3];
     spectrum_to_rgb(l, swl, rgb);
+    if (!rgb_finite_or_count(rgb)) return;
     std::lock_guard<std::mutex> g(locks.m[idx & 255]);
     double* p = &film.splats[3 * idx];
     p[0] += rgb[0];

@@ -171,6 +171,8 @@ int orc_render(orc_scene* s, const ptgpu_camera_desc* cam, const ptgpu_integrato
     return 0;
 }
 
+uint64_t orc_nonfinite_samples(void) { return nonfinite_samples().load(); }  // dropped since the library was loaded
+
 // ---- unit hooks (tests/test_oracle_units.py)
 void orc_pcg_stream(uint64_t x, uint64_t y, uint64_t i, uint32_t n, uint32_t* out_u32) {
     Sampler s;

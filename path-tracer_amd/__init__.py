@@ -336,9 +336,9 @@ class Context:
 
     def guard_counts(self):
         """How often a documented safety limit cut something short since the context was created (ptgpu_guard_counts)."""
-        out = (C.c_uint64 * 3)()
+        out = (C.c_uint64 * 4)()
         self._check(self.lib.ptgpu_guard_counts(self.handle, out))
-        return {"pass_through": out[0], "vertex_store": out[1], "quad_level": out[2]}
+        return {"pass_through": out[0], "vertex_store": out[1], "quad_level": out[2], "non_finite": out[3]}
 
     def kernel_times(self):
         """{stage: (total_ms, launches)} of the last render with profiling on."""

@@ -137,7 +137,14 @@ constexpr uint32_t kLightFilms = 16;
 // Float atomics run at the memory side at a fixed rate of 64-byte requests (MI355X_MICROARCH.md "Global float
 // atomics"): one lane per pixel makes three instructions of 64 single-double requests each; dealing the three
 // channels of a pixel to three neighbouring lanes makes each pixel's 24 bytes (and neighbouring pixels) one request.
-PT_D void film_add_rgb_wave(double* film, uint32_t pixel, const double rgb[3], bool want) {
+// A non-finite sample is dropped and counted (kGuardNonFinite): the reference asserts on it in `path` (path_tracer.rs:46)
+// and would poison the pixel for good in the other integrators. It happens: a bounce that lands on its own origin (an
+// edge shared by two triangles, t ~ 0) makes AreaLight::pdf_li_solid_angle 0/0 in the MIS weight of the next emitter hit.
+PT_D void film_add_rgb_wave(double* film, uint32_t pixel, const double rgb[3], bool want, uint32_t* guards) {
+    if (want && !(isfinite(rgb[0]) && isfinite(rgb[1]) && isfinite(rgb[2]))) {
+        want = false;
+        atomicAdd(guards + kGuardNonFinite, 1u);
+    }
     if (__ballot(want) == 0ull) return;
     const uint32_t lane = __lane_id();
 #pragma unroll
@@ -156,7 +163,7 @@ PT_D void film_add_wave(const SceneDev& sc, double* film, const float4* lambda_t
         const Lambdas wl = load_lambdas(lambda_tab, row, true);
         spec_to_rgb(l, wl, sec_term, sc.cie_xyz, rgb);
     }
-    film_add_rgb_wave(film, pixel, rgb, want);
+    film_add_rgb_wave(film, pixel, rgb, want, sc.guards);
 }
 
 struct RenderParams {
@@ -477,7 +484,7 @@ __global__ __launch_bounds__(kBlock, 8) void k_occlude_path(SceneDev sc, RenderP
                 store_spec(st.L0, st.L1, slot, L);
             }
         }
-        film_add_rgb_wave(rp.film, pixel, rgb, to_film);
+        film_add_rgb_wave(rp.film, pixel, rgb, to_film, sc.guards);
     }
     if (CENSUS) census_add(census, 2, cn, ct);
 }
@@ -663,7 +670,7 @@ __global__ __launch_bounds__(kBlock) void k_occlude_splat(SceneDev sc, RenderPar
                 visible = true;
             }
         }
-        film_add_rgb_wave(rp.film + (size_t)(blockIdx.x % rp.film_copies) * kFilmStride * rp.n_pixels, pixel, rgb, visible);
+        film_add_rgb_wave(rp.film + (size_t)(blockIdx.x % rp.film_copies) * kFilmStride * rp.n_pixels, pixel, rgb, visible, sc.guards);
     }
     if (CENSUS) census_add(census, 2, cn, ct);
 }

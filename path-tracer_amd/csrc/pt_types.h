@@ -69,7 +69,8 @@ struct SceneDev {
 enum { kGuardPassThrough = 0,   // a path ended after kMaxPassThrough consecutive pass-through crossings (pt_state.h)
        kGuardVertexStore = 1,   // a guided path vertex beyond the vertex store's rows was dropped (cannot happen: rows = max_depth + 1)
        kGuardQuadLevel = 2,     // the refinement declined to split a quadtree cell at level kMaxQuadLevel (pt_guided.h)
-       kNumGuards = 3 };
+       kGuardNonFinite = 3,     // a sample whose radiance is not finite was dropped instead of added to the film (pt_kernels.h: film_add_rgb_wave)
+       kNumGuards = 4 };
 
 struct CameraDev {
     Mat4 c2w, w2c;

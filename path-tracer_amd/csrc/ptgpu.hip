@@ -639,7 +639,7 @@ int ptgpu_census(ptgpu_ctx* c, uint64_t out[4]) {
     for (int i = 0; i < 4; i++) out[i] = h[i];
     return PTGPU_OK;
 }
-int ptgpu_guard_counts(ptgpu_ctx* c, uint64_t out[3]) {
+int ptgpu_guard_counts(ptgpu_ctx* c, uint64_t out[4]) {
     if (!c || !out) return fail(PTGPU_E_INVALID, "guard_counts: NULL argument");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));

@@ -34,6 +34,7 @@ def load():
         lib.orc_fresnel.argtypes = [C.c_float, C.c_float]
         lib.orc_complex_fresnel.restype = C.c_float
         lib.orc_complex_fresnel.argtypes = [C.c_float, C.c_float, C.c_float]
+        lib.orc_nonfinite_samples.restype = C.c_uint64
         lib.orc_sdtree_fresh.restype = C.c_void_p
         lib.orc_sdtree_fresh.argtypes = [C.c_void_p, C.c_float]
         lib.orc_sdtree_create.restype = C.c_void_p
@@ -197,6 +198,19 @@ def canonical(t: dict, spatial_threshold: float = 1000.0) -> dict:
         return h.export()
     finally:
         h.close()
+
+
+def render_sharded(oscene: OracleScene, cam, integrator, spp, workers=8):
+    """path / lightpath on an image of a single 16 x 16 tile would run on one thread (the reference parallelises over
+    tiles): render the sample-index shards i % workers == k concurrently instead (one oracle thread each; ctypes drops
+    the GIL) and add the films — every (pixel, sample) has its own RNG stream, so the sum is the unsharded render."""
+    from concurrent.futures import ThreadPoolExecutor
+    workers = max(1, min(workers, spp))
+    with ThreadPoolExecutor(workers) as ex:
+        parts = list(ex.map(lambda k: oscene.render(cam, integrator, spp, shard_index=k, shard_count=workers, n_threads=1), range(workers)))
+    film = sum(p[0] for p in parts)
+    stats = {k: sum(p[2][k] for p in parts) for k in parts[0][2]}
+    return film, parts[0][1], stats
 
 
 def rel_mse(img, ref):

@@ -2,6 +2,9 @@
 from __future__ import annotations
 
 import numpy as np
+from pathlib import Path
+
+REPO = Path(__file__).resolve().parent.parent
 
 import path_tracer_amd as pt
 

@@ -99,22 +99,27 @@ def test_hits_on_shipped_scenes(gpu_ctx, name):
 
 
 # ------------------------------------------------------------------ furnace (README.md:6): RGB [1,1,1]
-@pytest.mark.parametrize("kind,integrator,mode", [
-    ("plain", pt.INTEGRATOR_PATH, pt.MODE_PT), ("plain", pt.INTEGRATOR_PATH, pt.MODE_NEE), ("plain", pt.INTEGRATOR_PATH, pt.MODE_MIS),
-    ("glass", pt.INTEGRATOR_PATH, pt.MODE_MIS), ("skip", pt.INTEGRATOR_PATH, pt.MODE_MIS), ("plain", pt.INTEGRATOR_LIGHTPATH, pt.MODE_MIS),
-])
-def test_gpu_furnace_is_white(gpu_ctx, kind, integrator, mode):
-    sc = su.furnace_scene(kind)
-    gpu_ctx.set_scene(sc)
-    light = integrator == pt.INTEGRATOR_LIGHTPATH
-    gpu_ctx.set_camera(pt.make_camera(su.IDENTITY, 79.5 if light else 19.5, 16, 16))
-    spp = 65536 if light else 4096  # the GPU can afford far more samples than scenes-test's 64
-    # every crossing of the index-matched sphere costs two bounces: give the glass variant the depth to converge
-    depth = 64 if kind == "glass" else 16
-    film, scale, st = gpu_ctx.render(pt.make_integrator(integrator, depth, mode), spp)
+FURNACE_SCENES = ["simple_pt_white_sphere", "simple_nee_white_sphere", "simple_mis_white_sphere", "simple_pt_white_sphere_glass",
+                  "simple_nee_white_sphere_glass", "simple_mis_white_sphere_glass", "simple_mis_white_sphere_skip", "lt_white_sphere"]
+
+
+@pytest.mark.parametrize("name", FURNACE_SCENES)
+def test_gpu_furnace_is_white(gpu_ctx, name):
+    """All eight fixtures of pt/scenes-test, restated as scene_v3.xml (tools/make_furnace_scenes.py) and read by the real
+    loader: embedded icosphere_6.ply (20 480 triangles), file PLY with to_world scale, mirrored to_world on the inner
+    spheres, a shape without <ref> for `skip`, fov 19.5 / 79.5, 16 x 16. north_star: RGB [1, 1, 1] within 1e-3."""
+    glass = name.endswith("_glass")
+    # Every crossing of the index-matched sphere costs two of the 16 bounces the fixture allows: at depth 16 the glass
+    # variants are short of 1 by the energy of the cut-off tail (2e-3, on the oracle as well); they get the depth to converge.
+    sc = pt.LoadedScene(name, collection=su.REPO / "scenes-test", **({"max_depth": 64} if glass else {}))
+    assert (sc.camera.resx, sc.camera.resy, sc.spp) == (16, 16, 64) and sc.integrator.max_depth == (64 if glass else 16)
+    gpu_ctx.load(sc)
+    light = sc.integrator.kind == pt.INTEGRATOR_LIGHTPATH
+    spp = (1 << 20) if light else 4096   # the GPU can afford far more samples than the fixtures' 64
+    film, scale, st = gpu_ctx.render(sc.integrator, spp)
     mean = (film * scale).mean(axis=(0, 1))
     assert st["samples"] == 16 * 16 * spp
-    assert np.abs(mean - 1.0).max() < 1e-3 + (4e-3 if light else 0.0), mean   # north_star: within 1e-3
+    assert np.abs(mean - 1.0).max() < 1e-3, mean
 
 
 # ------------------------------------------------------------------ images vs the oracle
