@@ -1,13 +1,17 @@
 #!/usr/bin/env python3
 """bench.py — headline benchmark: Msamples/s of the `guided` integrator on cornell-box-guided (BASELINE.json metric,
-configs[3]: 512x512, 512 spp per GPU, max_depth 16, SD-tree statistics all-reduced over RCCL after each wave).
+configs[3]: 512x512 @ 512 spp, max_depth 16, on 1/2/4/8 MI355X with the SD-tree statistics all-reduced over RCCL).
 
-    python bench.py --gpus N --steps K --warmup W [--workload guided|path|veach-mis|lightpath]
+    python bench.py --gpus N --steps K --warmup W [--workload guided|path|veach-mis|lightpath|guided-large|guided-bidir]
+                    [--scaling strong|weak]
 
-A "step" is one complete render of the workload through the C ABI (all waves, the SD-tree refinement between them included). With N > 1
-(launched by torch.distributed.run, one rank per GPU) every rank traces its share of each wave's (pass, tile) pairs,
-the collector statistics are summed with an RCCL all-reduce after every wave and the films with one reduce at the
-end. Scaling is WEAK: the sample budget grows with N (spp = 512 * N), per-GPU work stays at 512 spp worth of paths.
+A "step" is one complete render of the workload through the C ABI (all waves, the SD-tree refinement between them
+included). With --gpus N > 1 and no launcher around it (WORLD_SIZE unset) this script starts the N rank processes itself
+(python -m torch.distributed.run, before anything touches the GPU); under torch.distributed.run it is one rank. Every
+rank traces its share of each wave's (pass, tile) pairs, the collector statistics are summed with an RCCL all-reduce
+after every wave and the films with one reduce (from the library's device buffer) at the end.
+Scaling is STRONG by default — the job is the fixed 512-spp render BASELINE configs[3] names, dealt over N GPUs — and the
+weak figure (spp = 512 * N, per-GPU work fixed) is measured after the timed region and reported beside it.
 Rank 0 prints ONE JSON line.
 """
 from __future__ import annotations
@@ -26,16 +30,64 @@ sys.path.insert(0, str(REPO / "tests"))
 import numpy as np  # noqa: E402
 
 WORKLOADS = {
-    # name: (scene, integrator override, resx, resy, spp per GPU, max_depth)
+    # name: (scene, integrator override, resx, resy, spp, max_depth)
     "guided": ("cornell-box-guided", "guided", 512, 512, 512, 16),     # BASELINE configs[3] (shipped XML values)
     "path": ("cornell-box", "path", 512, 512, 64, 8),                  # configs[0]
     "veach-mis": ("veach-mis", "path", 1280, 720, 1024, 3),            # configs[1]
     "lightpath": ("cornell-box", "lightpath", 512, 512, 512, 16),      # configs[2]
-    "guided-large": ("veach-mis", "guided", 1280, 720, 512, 32),       # configs[4]: largest shipped scene (61 492 triangles), 4096 spp over 8 GPUs
+    "guided-large": ("veach-mis", "guided", 1280, 720, 512, 32),       # configs[4]: largest shipped scene (61 492 triangles); 4096 spp over 8 GPUs = 512 per GPU
     "guided-bidir": ("veach-bidir", "guided", 512, 512, 512, 32),      # configs[4], the other reading: hardest transport
 }
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+
+# Compulsory HBM stream bytes per unit of each stage: {stage: (SURVEY §8d figure with S = 128 B of path state, the bytes the
+# actual layout moves)}; DESIGN.md §4. BVH node and triangle reads are NOT in here: they are served by LDS / L1 / L2
+# (the whole Cornell BVH is 1.5 KB) and are reported separately as "cache_served".
+def stage_bytes(stage, guided, light, segs, ext, shadow, samples):
+    if stage == "shade":
+        survey = segs * (2 * 128 + 16 + 32 + (128 if guided else 0)) + shadow * 36
+        # guided: 80 B of state each way + 24 B hit + ~96 B of vertex line + 32 B shadow entry; path/lightpath: 128 B each way
+        layout = segs * ((2 * 80 + 24 + 96) if guided else (2 * 128 + 24)) + shadow * (32 if guided else 64)
+    elif stage == "extend":
+        survey, layout = ext * (32 + 16), ext * (32 + 24)
+    elif stage == "occlude":
+        survey = shadow * (36 + 64)
+        layout = shadow * ((32 + 4) if guided else (64 + 32))
+    elif stage == "guide_record":
+        survey = layout = segs * (128 + 2 * 40 + 24 + 2 * 16)
+    else:
+        survey = layout = samples * (80 if guided else 128)
+    return survey, layout
+
+
+def dry_run(args) -> int:
+    """Launcher rehearsal without a render: process group (RCCL when every rank has a GPU, gloo otherwise), one all-reduce,
+    ONE JSON line from rank 0 with the number of ranks the collective saw."""
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    seen = 1
+    backend = "none"
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        gpu = torch.cuda.device_count() >= world
+        backend = "nccl" if gpu else "gloo"
+        if gpu:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
+        t = torch.ones(1, device=torch.device("cuda", local_rank) if gpu else "cpu")
+        dist.all_reduce(t)
+        seen = int(t.item())
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": seen, "requested": args.gpus, "backend": backend, "scaling": args.scaling}), flush=True)
+    return 0
 
 
 def main() -> int:
@@ -44,10 +96,25 @@ def main() -> int:
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="guided", choices=sorted(WORKLOADS))
-    ap.add_argument("--spp", type=int, default=0, help="override spp per GPU")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"], help="N > 1: fixed job dealt over N GPUs (default) or spp x N")
+    ap.add_argument("--spp", type=int, default=0, help="override the workload's spp")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--census", action="store_true", help="also count BVH nodes/triangles per ray (extra untimed render)")
+    ap.add_argument("--dry-run", action="store_true", help="launcher / process-group rehearsal only, no render (runs without a GPU)")
     args = ap.parse_args()
+
+    # ---- N ranks: started here when no launcher did it. Nothing above or in launch_ranks touches HIP or torch.cuda.
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        from path_tracer_amd import multi_gpu as mg
+        return mg.launch_ranks(args.gpus, str(Path(__file__).resolve()), sys.argv[1:])
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        print(f"[bench] --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks: refusing to report one as the other", file=sys.stderr)
+        return 2
+    if args.dry_run:
+        return dry_run(args)
 
     # The contract is ONE JSON line on stdout. Native libraries write banners there too (RCCL prints its version block
     # on rank 0 at communicator creation), so file descriptor 1 points at stderr for the whole run and the result line is
@@ -62,9 +129,9 @@ def main() -> int:
     import path_tracer_amd as pt
     from path_tracer_amd import multi_gpu as mg
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if torch.cuda.device_count() < world:
+        print(f"[bench] {world} ranks but {torch.cuda.device_count()} GPUs visible", file=sys.stderr)
+        return 2
     # PT_BENCH_FORCE_DIST=1: rehearse the RCCL code path (process group, in-place all-reduce of the library's statistics
     # buffer, film reduce) with a one-rank group on a one-GPU box
     force_dist = world == 1 and os.environ.get("PT_BENCH_FORCE_DIST") == "1"
@@ -77,27 +144,26 @@ def main() -> int:
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     use_dist = world > 1 or force_dist
-    if world != args.gpus and rank == 0:
-        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    n_ranks_seen = dist.get_world_size() if use_dist else 1
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
-    scene_name, integrator, resx, resy, spp_per_gpu, max_depth = WORKLOADS[args.workload]
+    scene_name, integrator, resx, resy, base_spp, max_depth = WORKLOADS[args.workload]
     if args.spp:
-        spp_per_gpu = args.spp
-    spp = spp_per_gpu * world  # weak scaling: the sample budget grows with the number of GPUs
+        base_spp = args.spp
+    spp = base_spp * world if args.scaling == "weak" else base_spp
     sc = pt.LoadedScene(scene_name, resx=resx, resy=resy, spp=spp, max_depth=max_depth, integrator=integrator)
     ctx = pt.Context(local_rank)
     ctx.load(sc)
     integ = pt.IntegratorDesc.from_buffer_copy(sc.integrator)
     guided = integ.kind == pt.INTEGRATOR_GUIDED
+    light = integ.kind == pt.INTEGRATOR_LIGHTPATH
     film_dev = torch.zeros((resy, resx, 3), dtype=torch.float64, device=dev) if use_dist else None
-
     wrap = mg.device_stats_tensor(torch, dev)
 
-    def step():
-        """One render of the whole workload; returns (film sums on rank 0, film_scale, stats of this rank)."""
-        return mg.render_sharded(ctx, integ, spp, rank, world, guided, dist=dist, wrap_stats=wrap, film_buf=film_dev,
+    def step(n_spp):
+        """One render of the whole job; returns (film sums on rank 0, film_scale, stats of this rank)."""
+        return mg.render_sharded(ctx, integ, n_spp, rank, world, guided, dist=dist, wrap_stats=wrap, film_buf=film_dev,
                                  sync=lambda: torch.cuda.synchronize(dev), collectives=use_dist)
 
     def fence():
@@ -105,32 +171,50 @@ def main() -> int:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    def timed(n_spp, n_steps, profile):
+        """n_steps renders between two fences; max over ranks. -> (seconds, totals over ranks, last stats, stage ms, stage launches)"""
+        stage_ms = {k: 0.0 for k in pt.KERNEL_NAMES}
+        stage_n = {k: 0 for k in pt.KERNEL_NAMES}
+        totals = {"samples": 0, "extend_rays": 0, "shadow_rays": 0, "segments": 0}
+        if profile:
+            ctx.set_profiling(True)  # HIP-event pairs on the library's own streams, recorded without host waits
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(n_steps):
+            _, _, st = step(n_spp)
+            for k in totals:
+                totals[k] += st[k]
+            if profile:
+                for k, (ms, n) in ctx.kernel_times().items():
+                    stage_ms[k] += ms
+                    stage_n[k] += n
+        fence()
+        elapsed = time.perf_counter() - t0
+        ctx.set_profiling(False)
+        if use_dist:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+            tot = torch.tensor([totals[k] for k in ("samples", "extend_rays", "shadow_rays", "segments")], dtype=torch.float64, device=dev)
+            dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+            for i, k in enumerate(("samples", "extend_rays", "shadow_rays", "segments")):
+                totals[k] = int(tot[i].item())
+        return elapsed, totals, st, stage_ms, stage_n
+
     for _ in range(args.warmup):
-        step()
-    ctx.set_profiling(True)  # HIP-event pairs on the library's own stream, recorded without host waits
-    stage_ms = {k: 0.0 for k in pt.KERNEL_NAMES}
-    stage_n = {k: 0 for k in pt.KERNEL_NAMES}
-    totals = {"samples": 0, "extend_rays": 0, "shadow_rays": 0, "segments": 0}
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        film, scale, st = step()
-        for k in totals:
-            totals[k] += st[k]
-        for k, (ms, n) in ctx.kernel_times().items():
-            stage_ms[k] += ms
-            stage_n[k] += n
-    fence()
-    elapsed = time.perf_counter() - t0
-    ctx.set_profiling(False)
-    if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        tot = torch.tensor([totals[k] for k in ("samples", "extend_rays", "shadow_rays", "segments")], dtype=torch.float64, device=dev)
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-        for i, k in enumerate(("samples", "extend_rays", "shadow_rays", "segments")):
-            totals[k] = int(tot[i].item())
+        step(spp)
+    elapsed, totals, st, stage_ms, stage_n = timed(spp, args.steps, True)
+
+    # the other scaling mode, measured beside the headline (N > 1 only; at N = 1 they are the same job)
+    other = None
+    if world > 1:
+        o_spp = base_spp if args.scaling == "weak" else base_spp * world
+        step(o_spp)
+        o_steps = max(1, min(args.steps, 3))
+        o_elapsed, o_tot, _, _, _ = timed(o_spp, o_steps, False)
+        other = {"scaling": "weak" if args.scaling == "strong" else "strong", "value": round(resx * resy * o_spp * o_steps / o_elapsed * 1e-6, 3),
+                 "unit": "Msamples/s", "spp_total": o_spp, "steps": o_steps, "ms_per_step": round(o_elapsed / o_steps * 1e3, 3)}
+        assert o_tot["samples"] == resx * resy * o_spp * o_steps
 
     if rank != 0:
         if world > 1:
@@ -146,57 +230,47 @@ def main() -> int:
     # ---- roofline of the dominant kernel (rank 0's launches, HIP events over the timed region)
     kernel_stages = [k for k in ("raygen", "extend", "shade", "occlude", "guide_record") if stage_n[k] > 0]
     dom = max(kernel_stages, key=lambda k: stage_ms[k])
-    my_segments = st["segments"] * args.steps
-    my_extend = st["extend_rays"] * args.steps
-    my_shadow = st["shadow_rays"] * args.steps
+    my = {k: st[k] * args.steps for k in ("segments", "extend_rays", "shadow_rays", "samples")}
+    survey_bytes, layout_bytes = stage_bytes(dom, guided, light, my["segments"], my["extend_rays"], my["shadow_rays"], my["samples"])
     census = None
     if world == 1 and (args.census or dom in ("extend", "occlude")):
         ctx.set_census(True)   # instrumented kernel variants, one extra untimed render
-        step()
+        step(spp)
         census = ctx.census()
         ctx.set_census(False)
-    # algorithmic bytes per unit (DESIGN.md "Kernels and rooflines"; SURVEY.md §8d split per stage)
-    if dom == "shade":
-        # per shaded segment: path state read + write (2 x 128 B), hit read 16 B, next ray write 32 B, shadow ray write 36 B per
-        # NEE sample, and for guided one 128-B PathVertex per segment (tree node reads not counted: conservative)
-        alg_bytes = my_segments * (2 * 128 + 16 + 32 + (128 if guided else 0)) + my_shadow * 36
-    elif dom == "extend":
-        per_ray = 32 + 16
-        if census:
-            per_ray += (32 * census["extend_nodes"] + 36 * census["extend_tris"]) / max(1, st["extend_rays"])
-        alg_bytes = my_extend * per_ray
-    elif dom == "occlude":
-        per_ray = 36 + 64
-        if census:
-            per_ray += (32 * census["occlude_nodes"] + 36 * census["occlude_tris"]) / max(1, st["shadow_rays"])
-        alg_bytes = my_shadow * per_ray
-    elif dom == "guide_record":
-        alg_bytes = my_segments * (128 + 4 * 8)
-    else:
-        alg_bytes = st["samples"] * args.steps * 128
     launches = max(1, stage_n[dom])
     avg_ms = stage_ms[dom] / launches
-    achieved = alg_bytes / launches / (avg_ms * 1e-3) * 1e-9 if avg_ms > 0 else 0.0
-    roofline = {"bound": "hbm", "kernel": {"extend": "k_extend", "shade": "k_shade_guided" if guided else ("k_shade_light" if integ.kind == pt.INTEGRATOR_LIGHTPATH else "k_shade_path"),
-                                           "occlude": "k_occlude", "guide_record": "k_guide_record", "raygen": "k_raygen"}[dom],
-                "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                "avg_launch_ms": round(avg_ms, 4), "launches": launches, "alg_bytes_per_launch": int(alg_bytes / launches),
+    gbs = lambda b: b / launches / (avg_ms * 1e-3) * 1e-9 if avg_ms > 0 else 0.0  # noqa: E731
+    achieved = gbs(survey_bytes)
+    kernel = {"extend": "k_extend", "shade": "k_shade_guided" if guided else ("k_shade_light" if light else "k_shade_path"),
+              "occlude": "k_occlude_guided" if guided else ("k_occlude_splat" if light else "k_occlude_path"),
+              "guide_record": "k_guide_scan+locate+scatter+splat_bins", "raygen": "k_raygen"}[dom]
+    roofline = {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                "bytes_model": "compulsory stream bytes per SURVEY 8d (path state priced at S = 128 B); BVH node/triangle reads excluded (cache-served)",
+                "achieved_actual_layout": round(gbs(layout_bytes), 2), "frac_actual_layout": round(gbs(layout_bytes) / HBM_PEAK_GBS, 5),
+                "avg_launch_ms": round(avg_ms, 4), "launches": launches, "alg_bytes_per_launch": int(survey_bytes / launches),
+                "layout_bytes_per_launch": int(layout_bytes / launches),
                 "stage_ms_per_step": {k: round(stage_ms[k] / args.steps, 2) for k in stage_ms if stage_n[k]}}
     # HBM-side bytes per launch of the same kernel on the same workload, from the committed rocprofv3 --pmc passes
     # (tools/gpu_traffic.sh: FETCH_SIZE x2 + WRITE_SIZE, MI355X_MICROARCH.md "HBM"); counters cannot be read in-process.
-    if args.workload == "guided" and not args.spp:
-        cands = sorted((REPO / "profiles").glob("*_guided_traffic.json"))
+    if not args.spp and world == 1:
+        cands = sorted((REPO / "profiles").glob(f"*_{args.workload}_traffic.json"))
         if cands:
             tj = json.loads(cands[-1].read_text())
             for kname, d in tj.get("kernels", {}).items():
-                if roofline["kernel"] in kname:
+                if kernel.split("+")[0] in kname:
                     roofline["traffic"] = int(d["hbm_bytes_per_launch"])
                     roofline["traffic_source"] = f"profiles/{cands[-1].name}"
     if census:
-        roofline["census"] = {"nodes_per_extend_ray": round(census["extend_nodes"] / max(1, st["extend_rays"]), 2),
-                              "tris_per_extend_ray": round(census["extend_tris"] / max(1, st["extend_rays"]), 2),
-                              "nodes_per_shadow_ray": round(census["occlude_nodes"] / max(1, st["shadow_rays"]), 2),
-                              "tris_per_shadow_ray": round(census["occlude_tris"] / max(1, st["shadow_rays"]), 2)}
+        n_ext, n_sh = max(1, st["extend_rays"]), max(1, st["shadow_rays"])
+        roofline["census"] = {"nodes_per_extend_ray": round(census["extend_nodes"] / n_ext, 2), "tris_per_extend_ray": round(census["extend_tris"] / n_ext, 2),
+                              "nodes_per_shadow_ray": round(census["occlude_nodes"] / n_sh, 2), "tris_per_shadow_ray": round(census["occlude_tris"] / n_sh, 2)}
+        if dom in ("extend", "occlude"):
+            kn, kt = ("extend_nodes", "extend_tris") if dom == "extend" else ("occlude_nodes", "occlude_tris")
+            served = (32 * census[kn] + 36 * census[kt]) * args.steps
+            roofline["cache_served"] = {"bytes_per_launch": int(served / launches), "gbs": round(gbs(served), 1),
+                                        "note": "BVH nodes (32 B) and triangles (36 B) the walk reads from LDS / L1 / L2, not charged to HBM"}
 
     # ---- CPU baseline: the oracle (a port of the reference's algorithm), bounded sample, rank 0 at N=1 only
     cpu = None
@@ -210,40 +284,37 @@ def main() -> int:
         dt = time.perf_counter() - t0
         cpu = {"value": round(cst["samples"] / dt * 1e-6, 4), "unit": "Msamples/s", "cores": cores, "kind": "port",
                "sample": f"{scene_name} {resx}x{resy} @ {cpu_spp} spp, {integrator}, max_depth {max_depth} ({dt:.1f} s; C++ restatement of the reference, "
-                         "the Rust reference cannot be built in this image)"}
+                         "the Rust reference cannot be built in this image; parity with the Rust binary is pinned by the 8 furnace fixtures only)"}
 
-    # ---- image check next to the throughput number (BASELINE metric: "relMSE vs CPU reference"): the same scene at 128x128,
-    # GPU at 64 spp against the CPU oracle at 4x the samples; relMSE = mean((I-R)^2 / (R^2 + 1e-2)) on the linear film.
-    # Monte Carlo noise (fireflies behind the glass cube) dominates that mean at 64 spp, so the yardstick printed next to
-    # it is the ORACLE's own 64-spp image against the same reference: the GPU is right when the two agree. "trimmed" drops
-    # the 0.1 % largest per-pixel terms. (path/lightpath walk the oracle's very paths: tests/ compare them at equal spp.)
+    # ---- image check next to the throughput number (BASELINE metric: "relMSE vs CPU reference"): the Cornell box at 64 x 64,
+    # GPU at 1 024 spp against the CPU oracle's converged image (16 384 spp, tests/golden/converged_cornell_64.npz, written
+    # by tests/golden/make_converged.py); the yardstick beside it is the oracle's own relMSE at the same 1 024 spp.
     relmse = None
-    if cpu is not None and args.workload in ("guided", "path", "lightpath"):
-        def rel_terms(img, ref):
-            return ((img - ref) ** 2 / (ref ** 2 + 1e-2)).mean(axis=2).ravel()
-
-        def summary(img, ref):
-            t = np.sort(rel_terms(img, ref))
-            return {"relmse": round(float(t.mean()), 5), "relmse_trimmed": round(float(t[: int(len(t) * 0.999)].mean()), 5)}
-
-        small = pt.LoadedScene(scene_name, resx=128, resy=128, spp=64, max_depth=max_depth, integrator=integrator)
+    gold = REPO / "tests" / "golden" / "converged_cornell_64.npz"
+    key = {"guided": "guided", "path": "path", "lightpath": "lightpath"}.get(args.workload)
+    if world == 1 and key and gold.exists():
+        g = np.load(gold)
+        small = pt.LoadedScene(scene_name, resx=64, resy=64, max_depth=16, integrator=integrator)
         ctx.load(small)
-        gf, gs, _ = ctx.render(integ, 64)
-        osc = ob.OracleScene(small)
-        rf, rs, _ = osc.render(small.camera, integ, 256, n_threads=cores)
-        cf, cs, _ = osc.render(small.camera, integ, 64, n_threads=cores)
-        relmse = {"gpu_64spp_vs_oracle_256spp": summary(gf * gs, rf * rs), "oracle_64spp_vs_oracle_256spp": summary(cf * cs, rf * rs), "res": "128x128"}
+        gf, gs, _ = ctx.render(integ, int(g[f"{key}_spp"]))
+        ref = g[f"{key}_ref"]
+        relmse = {"gpu_vs_converged_oracle": round(float(np.mean((gf * gs - ref) ** 2 / (ref ** 2 + 1e-2))), 5),
+                  "oracle_vs_converged_oracle": round(float(g[f"{key}_oracle_relmse"]), 5), "spp": int(g[f"{key}_spp"]),
+                  "reference_spp": int(g[f"{key}_ref_spp"]), "res": "64x64", "max_depth": 16,
+                  "note": "relMSE = mean((I-R)^2 / (R^2 + 1e-2)) on the linear film; parity with the Rust binary itself is unpinned beyond the furnace fixtures"}
         ctx.load(sc)
 
     out = {
-        "metric": "Msamples/s", "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "metric": "Msamples/s", "value": round(value, 3), "unit": "Msamples/s", "n_gpus": n_ranks_seen, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{scene_name}, integrator={integrator}, {resx}x{resy} @ {spp_per_gpu} spp per GPU ({spp} total), max_depth {max_depth}",
+        "config": {"workload": f"{scene_name}, integrator={integrator}, {resx}x{resy} @ {spp} spp total ({args.scaling} scaling over {world} GPU(s)), max_depth {max_depth}",
                    "parallelism": f"shard{world}: (pass, tile) pairs round-robin, RCCL all-reduce of SD-tree statistics per wave" if guided else f"shard{world}: sample index mod N",
                    "mrays_per_s": round(mrays, 1), "stree_nodes": st.get("stree_nodes", 0), "dtree_nodes": st.get("dtree_nodes", 0)},
         "roofline": roofline, "cpu_baseline": cpu, "relmse_vs_cpu_oracle": relmse,
     }
+    if other:
+        out["other_scaling"] = other
     sys.stdout.flush()
     os.write(result_fd, (json.dumps(out) + "\n").encode())
     if use_dist:

@@ -143,6 +143,11 @@ int ptgpu_guided_begin(ptgpu_ctx* ctx, const ptgpu_integrator_desc* integrator, 
 int ptgpu_guided_wave(ptgpu_ctx* ctx, uint32_t wave);
 int ptgpu_guided_stats(ptgpu_ctx* ctx, float** device_ptr_out, size_t* count_out);
 int ptgpu_guided_end(ptgpu_ctx* ctx, double* film_rgb_out, double* film_scale_out, ptgpu_stats* stats);
+/* Multi-GPU film reduce without a host round trip (no reference counterpart): after ptgpu_render[_shard] or
+ * ptgpu_guided_end returned (film_rgb_out may be NULL there to skip the download), the DEVICE pointer and element count
+ * (resx * resy * 3 doubles, same layout as film_rgb_out) of this context's film sums, e.g. for an in-place ncclReduce.
+ * Valid until the next render or camera_set on this context. */
+int ptgpu_film_device(ptgpu_ctx* ctx, double** device_ptr_out, size_t* count_out);
 /* Parity hook for the guided sampler (no reference counterpart as an API). Between two waves: draws n_probes random
  * points in the SD-tree of the wave just refined and, for each, (a) runs DTree::sample then DTree::pdf as two separate
  * descents (pt/src/integrator/path_guiding/dtree.rs:98-179) and (b) the single fused descent the shade kernel uses;

@@ -89,7 +89,7 @@ PTGPU_SYMBOLS = [
     "ptgpu_trace_batch", "ptgpu_occluded_batch", "ptgpu_scene_info", "ptgpu_scene_bvh", "ptgpu_set_profiling",
     "ptgpu_set_batch_paths", "ptgpu_kernel_times", "ptgpu_set_census", "ptgpu_census", "ptgpu_guided_selfcheck",
     "ptgpu_trace_batch_noalloc", "ptgpu_guided_tree_info", "ptgpu_guided_tree_download", "ptgpu_guided_probe",
-    "ptgpu_guided_record_batch", "ptgpu_guided_refine", "ptgpu_guard_counts",
+    "ptgpu_guided_record_batch", "ptgpu_guided_refine", "ptgpu_guard_counts", "ptgpu_film_device",
 ]
 PTHOST_SYMBOLS = [
     "pthost_last_error", "pthost_scene_load", "pthost_scene_free", "pthost_scene_desc", "pthost_camera_desc",
@@ -164,6 +164,7 @@ def load_gpu() -> C.CDLL:
         lib.ptgpu_set_batch_paths.argtypes = [C.c_void_p, C.c_uint32]
         lib.ptgpu_set_census.argtypes = [C.c_void_p, C.c_int]
         lib.ptgpu_census.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+        lib.ptgpu_film_device.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
         lib.ptgpu_guard_counts.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
         lib.ptgpu_kernel_times.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_uint32]
         _gpu = lib
@@ -380,15 +381,23 @@ class Context:
         self._check(self.lib.ptgpu_occluded_batch(self.handle, _fptr(a), _fptr(b), a.shape[0], out.ctypes.data_as(C.POINTER(C.c_uint8))))
         return out
 
-    def render(self, integrator: IntegratorDesc, spp: int, shard_index: int = 0, shard_count: int = 1):
-        """Integrator::render. Returns (film_sums (H,W,3) f64, film_scale, stats dict)."""
-        film = np.zeros((self.cam.resy, self.cam.resx, 3), dtype=np.float64)
+    def render(self, integrator: IntegratorDesc, spp: int, shard_index: int = 0, shard_count: int = 1, host_film: bool = True):
+        """Integrator::render. Returns (film_sums (H,W,3) f64, film_scale, stats dict); host_film=False leaves the film on the
+        device (film_device()) and returns None for it."""
+        film = np.zeros((self.cam.resy, self.cam.resx, 3), dtype=np.float64) if host_film else None
         scale = C.c_double()
         st = Stats()
         integ = IntegratorDesc.from_buffer_copy(integrator)
         self._check(self.lib.ptgpu_render_shard(self.handle, C.byref(integ), spp, shard_index, shard_count,
-                                                film.ctypes.data_as(C.POINTER(C.c_double)), C.byref(scale), C.byref(st)))
+                                                film.ctypes.data_as(C.POINTER(C.c_double)) if host_film else None, C.byref(scale), C.byref(st)))
         return film, scale.value, st.as_dict()
+
+    def film_device(self):
+        """(device pointer, double count) of the film sums of the last completed render (ptgpu_film_device)."""
+        p = C.c_void_p()
+        n = C.c_size_t()
+        self._check(self.lib.ptgpu_film_device(self.handle, C.byref(p), C.byref(n)))
+        return p.value, n.value
 
     # guided, wave by wave (multi-GPU drivers all-reduce guided_stats() between waves)
     def guided_begin(self, integrator: IntegratorDesc, spp: int, shard_index: int = 0, shard_count: int = 1) -> int:
@@ -467,11 +476,11 @@ class Context:
     def guided_refine(self):
         self._check(self.lib.ptgpu_guided_refine(self.handle))
 
-    def guided_end(self):
-        film = np.zeros((self.cam.resy, self.cam.resx, 3), dtype=np.float64)
+    def guided_end(self, host_film: bool = True):
+        film = np.zeros((self.cam.resy, self.cam.resx, 3), dtype=np.float64) if host_film else None
         scale = C.c_double()
         st = Stats()
-        self._check(self.lib.ptgpu_guided_end(self.handle, film.ctypes.data_as(C.POINTER(C.c_double)), C.byref(scale), C.byref(st)))
+        self._check(self.lib.ptgpu_guided_end(self.handle, film.ctypes.data_as(C.POINTER(C.c_double)) if host_film else None, C.byref(scale), C.byref(st)))
         return film, scale.value, st.as_dict()
 
 

@@ -160,6 +160,7 @@ struct ptgpu_ctx {
     uint64_t launches = 0;
     GuidedState* guided = nullptr;
     GuidedPersist* guided_persist = nullptr;
+    bool film_ready = false;           // d_film_packed holds the film of the last completed render
     unsigned char* scratch = nullptr;  // device address of `scratch` on this context's GPU (hipGetSymbolAddress)
 };
 
@@ -521,6 +522,7 @@ int ptgpu_camera_set(ptgpu_ctx* c, const ptgpu_camera_desc* cam) {
     d.resy = cam->resy;
     d.p = mat_point(d.c2w, mk3(0.0f, 0.0f, 0.0f));
     d.n = normalize(mat_vector(d.c2w, mk3(0.0f, 0.0f, 1.0f)));
+    c->film_ready = false;
     c->have_camera = true;
     return PTGPU_OK;
 }
@@ -637,6 +639,12 @@ int ptgpu_census(ptgpu_ctx* c, uint64_t out[4]) {
     unsigned long long h[4];
     HIP_TRY(hipMemcpy(h, c->d_census.p, sizeof(h), hipMemcpyDeviceToHost));
     for (int i = 0; i < 4; i++) out[i] = h[i];
+    return PTGPU_OK;
+}
+int ptgpu_film_device(ptgpu_ctx* c, double** device_ptr_out, size_t* count_out) {
+    if (!c || !c->film_ready) return fail(PTGPU_E_STATE, "film_device: no completed render");
+    if (device_ptr_out) *device_ptr_out = c->d_film_packed.p;
+    if (count_out) *count_out = 3 * (size_t)c->camera.resx * c->camera.resy;
     return PTGPU_OK;
 }
 int ptgpu_guard_counts(ptgpu_ctx* c, uint64_t out[4]) {
@@ -801,15 +809,16 @@ int check_render_args(ptgpu_ctx* c, const ptgpu_integrator_desc* integ, uint32_t
     return PTGPU_OK;
 }
 
+// Packs the device film into RGB sums (d_film_packed: what ptgpu_film_device exposes) and, when the caller wants a host
+// copy, downloads it.
 int download_film(ptgpu_ctx* c, double* film_out) {
-    if (film_out) {
-        const uint32_t npix = c->camera.resx * c->camera.resy;
-        HIP_TRY(c->d_film_packed.reserve(3 * (size_t)npix));
-        hipLaunchKernelGGL(k_pack_film, dim3((3 * npix + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, c->d_film.p, c->d_film_packed.p, npix, c->film_copies);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(film_out, c->d_film_packed.p, 3 * (size_t)npix * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    }
+    const uint32_t npix = c->camera.resx * c->camera.resy;
+    HIP_TRY(c->d_film_packed.reserve(3 * (size_t)npix));
+    hipLaunchKernelGGL(k_pack_film, dim3((3 * npix + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, c->d_film.p, c->d_film_packed.p, npix, c->film_copies);
+    HIP_TRY(hipGetLastError());
+    if (film_out) HIP_TRY(hipMemcpyAsync(film_out, c->d_film_packed.p, 3 * (size_t)npix * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    c->film_ready = true;
     return PTGPU_OK;
 }
 
@@ -827,6 +836,7 @@ int ptgpu_render_shard(ptgpu_ctx* c, const ptgpu_integrator_desc* integ, uint32_
     HIP_TRY(hipSetDevice(c->device));
     if (stats) memset(stats, 0, sizeof(*stats));
     reset_stage_times(c);
+    c->film_ready = false;
     const auto t0 = std::chrono::steady_clock::now();
     c->film_copies = integ->kind == PTGPU_INTEGRATOR_LIGHTPATH ? kLightFilms : 1;
     const size_t film_n = (size_t)c->camera.resx * c->camera.resy * kFilmStride * c->film_copies;

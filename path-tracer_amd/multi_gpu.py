@@ -6,11 +6,37 @@ loop is dealt over N GPUs without changing any sample:
   * guided: in every wave, tile t of pass k belongs to rank (t + k) % N (pt_guided.h: k_raygen_guided); after each wave
     but the last the collector statistics are summed IN PLACE on the library's buffer with one all_reduce, then every
     rank refines the same tree;
-  * the film sums are reduced onto rank 0 once at the end.
+  * the film sums are reduced onto rank 0 once at the end, from the library's device buffer (ptgpu_film_device): no
+    host round trip.
+launch_ranks() starts the N rank processes of a one-node job (python -m torch.distributed.run) from a parent that has
+not touched the GPU.
 """
 from __future__ import annotations
 
+import os
+import socket
+import subprocess
+import sys
+
 import numpy as np
+
+
+def free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n_ranks: int, script: str, argv, env=None, timeout=None) -> int:
+    """Runs `script argv...` as n_ranks processes of one node under torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* set for each; rendezvous on 127.0.0.1) and returns its exit code. The children inherit stdout, so the one
+    JSON line rank 0 prints is this process's output. Must be called BEFORE the caller makes any HIP / torch.cuda call:
+    a process that has initialised the GPU must not start or become another program on this pool."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), script, *argv]
+    e = dict(os.environ if env is None else env)
+    e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL over xGMI needs it on this pool
+    return subprocess.run(cmd, env=e, timeout=timeout).returncode
 
 
 def samples_of_shard(spp: int, rank: int, world: int) -> range:
@@ -26,13 +52,14 @@ def shard_of_pair(tile: int, pass_index: int, world: int) -> int:
 class DeviceArray:
     """Raw device pointer -> torch tensor (zero copy) through __cuda_array_interface__."""
 
-    def __init__(self, ptr, count):
-        self.__cuda_array_interface__ = {"shape": (count,), "typestr": "<f4", "data": (ptr, False), "version": 2}
+    def __init__(self, ptr, count, typestr="<f4"):
+        self.__cuda_array_interface__ = {"shape": (count,), "typestr": typestr, "data": (ptr, False), "version": 2}
 
 
 def device_stats_tensor(torch, dev):
-    """wrap(ptr, count) for a libptgpu context: a float32 tensor aliasing the library's statistics buffer."""
-    return lambda ptr, count: torch.as_tensor(DeviceArray(ptr, count), device=dev)
+    """wrap(ptr, count[, typestr]) for a libptgpu context: a tensor aliasing a device buffer of the library (float32
+    statistics by default, "<f8" for the film)."""
+    return lambda ptr, count, typestr="<f4": torch.as_tensor(DeviceArray(ptr, count, typestr), device=dev)
 
 
 def render_sharded(ctx, integ, spp, rank, world, guided, dist=None, wrap_stats=None, film_buf=None, sync=lambda: None, collectives=None):
@@ -47,6 +74,7 @@ def render_sharded(ctx, integ, spp, rank, world, guided, dist=None, wrap_stats=N
     """
     if collectives is None:
         collectives = world > 1
+    on_device = collectives and hasattr(ctx, "film_device")  # reduce straight from the library's film buffer
     if guided:
         n_waves = ctx.guided_begin(integ, spp, rank, world)
         for w in range(n_waves):
@@ -56,10 +84,17 @@ def render_sharded(ctx, integ, spp, rank, world, guided, dist=None, wrap_stats=N
                 t = wrap_stats(ptr, count)
                 dist.all_reduce(t, op=dist.ReduceOp.SUM)
                 sync()
-        film, scale, st = ctx.guided_end()
+        film, scale, st = ctx.guided_end(host_film=False) if on_device else ctx.guided_end()
     else:
-        film, scale, st = ctx.render(integ, spp, rank, world)
-    if collectives:
+        film, scale, st = ctx.render(integ, spp, rank, world, host_film=False) if on_device else ctx.render(integ, spp, rank, world)
+    if on_device:
+        ptr, count = ctx.film_device()
+        t = wrap_stats(ptr, count, "<f8")
+        dist.reduce(t, dst=0, op=dist.ReduceOp.SUM)
+        sync()
+        if rank == 0:
+            film = t.cpu().numpy().reshape(film_buf.shape).copy()
+    elif collectives:
         import torch
         film_buf.copy_(torch.from_numpy(np.ascontiguousarray(film)))
         dist.reduce(film_buf, dst=0, op=dist.ReduceOp.SUM)

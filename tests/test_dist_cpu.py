@@ -156,3 +156,29 @@ def test_shard_rules_balance():
                 for t in range(1024):
                     load[mg.shard_of_pair(t, k, world)] += 1
             assert max(load) - min(load) <= passes   # a one-pass wave still feeds every GPU
+
+
+# ------------------------------------------------------------------ bench.py as its own launcher
+def _bench(args, **env_extra):
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra)
+    return subprocess.run([sys.executable, str(REPO / "bench.py"), *args], env=env, capture_output=True, text=True, timeout=240)
+
+
+def test_bench_starts_its_own_ranks_when_no_launcher_did():
+    """`python bench.py --gpus 2` with WORLD_SIZE unset must run TWO ranks (torch.distributed.run started by the parent before
+    it touches any GPU) and rank 0 alone prints the one JSON line; --dry-run stops after the process group's first
+    all-reduce (gloo here: no GPU), which is what reports how many ranks the collective really saw."""
+    import json
+    r = _bench(["--gpus", "2", "--dry-run"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["requested"] == 2 and line["backend"] == "gloo" and line["scaling"] == "strong"
+
+
+def test_bench_refuses_a_world_size_that_is_not_what_was_asked_for():
+    r = _bench(["--gpus", "2", "--dry-run"], WORLD_SIZE="1", RANK="0")
+    assert r.returncode == 2 and "refusing" in r.stderr and not r.stdout.strip()
