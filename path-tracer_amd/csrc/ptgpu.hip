@@ -160,6 +160,7 @@ struct ptgpu_ctx {
     uint64_t launches = 0;
     GuidedState* guided = nullptr;
     GuidedPersist* guided_persist = nullptr;
+    bool direct_splat = false;         // PTGPU_DIRECT_SPLAT, sampled at the start of a wave
     bool film_ready = false;           // d_film_packed holds the film of the last completed render
     unsigned char* scratch = nullptr;  // device address of `scratch` on this context's GPU (hipGetSymbolAddress)
 };
@@ -179,15 +180,22 @@ namespace {
         else PT_LAUNCH_ONE_KIND(c, HIP_KERNEL_NAME(kernel<7>), grid, __VA_ARGS__);                                       \
     } while (0)
 
-int resident_grid(ptgpu_ctx* c, const void* kernel, int grid) {
+int resident_grid(ptgpu_ctx* c, const void* kernel, int grid, size_t dynamic_lds = 0) {
     auto it = c->resident_blocks.find(kernel);
     if (it == c->resident_blocks.end()) {
         int per_cu = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, 0) != hipSuccess || per_cu < 1) per_cu = 8;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, dynamic_lds) != hipSuccess || per_cu < 1) per_cu = dynamic_lds ? 1 : 8;
         it = c->resident_blocks.emplace(kernel, std::min(per_cu, 8)).first;
     }
     return std::min(grid, c->n_cus * it->second);
 }
+// Kernels that walk the BVH keep their traversal stacks (and small node arrays) in dynamic LDS sized from the scene's
+// tree depth (c->bvh_lds, 15 KB for the Cornell box, 35 KB at depth 25, 74 KB at the reference's limit of 64 levels): the
+// grid is what is resident with THAT much LDS per workgroup (the cache is per scene: ptgpu_scene_create clears it).
+#define PT_LAUNCH_WALK(c, kernel, grid, ...) \
+    hipLaunchKernelGGL(kernel, dim3(resident_grid((c), (const void*)kernel, (grid), (c)->bvh_lds)), dim3(kBlock), (c)->bvh_lds, (c)->stream, __VA_ARGS__)
+// Above 64 KB per workgroup a kernel must be told so before its first launch (up to the CU's 160 KB).
+constexpr size_t kLdsDefaultLimit = 64 * 1024, kLdsPerCu = 160 * 1024;
 
 int grid_for(const ptgpu_ctx* c, uint64_t n) {
     const uint64_t want = (n + kBlock - 1) / kBlock;
@@ -477,6 +485,15 @@ int ptgpu_scene_create(ptgpu_ctx* c, const ptgpu_scene_desc* desc) {
     s.bvh_stack = bvh_depth + 1;
     s.lds_nodes = (n_nodes * 32 <= kLdsNodeBudget) ? 1u : 0u;
     c->bvh_lds = (size_t)kBlock * (s.bvh_stack + 2 * kLeafQueue) * sizeof(uint32_t) + (s.lds_nodes ? n_nodes * 32 : 0);
+    c->resident_blocks.clear();
+    if (c->bvh_lds > kLdsPerCu) return fail(PTGPU_E_LIMIT, "scene_create: traversal stacks exceed the CU's LDS");
+    if (c->bvh_lds > kLdsDefaultLimit) {
+        const void* walkers[] = {(const void*)k_trace_batch<true>,    (const void*)k_trace_batch<false>,   (const void*)k_occluded_batch,
+                                 (const void*)k_extend<true>,         (const void*)k_extend<false>,        (const void*)k_occlude_path<true>,
+                                 (const void*)k_occlude_path<false>,  (const void*)k_occlude_splat<true>,  (const void*)k_occlude_splat<false>,
+                                 (const void*)k_occlude_guided<true>, (const void*)k_occlude_guided<false>};
+        for (const void* k : walkers) HIP_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->bvh_lds));
+    }
     s.bounds_lo = bvh.nodes[0].bounds.lo;
     s.bounds_hi = bvh.nodes[0].bounds.hi;
     c->have_scene = true;
@@ -562,9 +579,9 @@ int ptgpu_trace_batch(ptgpu_ctx* c, const float* rays, uint32_t n, ptgpu_hit* hi
     {
         StageTimer st(c, PTGPU_STAGE_EXTEND);
         if (c->census_on)
-            hipLaunchKernelGGL(k_trace_batch<true>, dim3(grid_for(c, n)), dim3(kBlock), c->bvh_lds, c->stream, c->scene, d_rays.p, n, d_hits.p, c->d_census.p);
+            PT_LAUNCH_WALK(c, HIP_KERNEL_NAME(k_trace_batch<true>), grid_for(c, n), c->scene, d_rays.p, n, d_hits.p, c->d_census.p);
         else
-            hipLaunchKernelGGL(k_trace_batch<false>, dim3(grid_for(c, n)), dim3(kBlock), c->bvh_lds, c->stream, c->scene, d_rays.p, n, d_hits.p, (unsigned long long*)nullptr);
+            PT_LAUNCH_WALK(c, HIP_KERNEL_NAME(k_trace_batch<false>), grid_for(c, n), c->scene, d_rays.p, n, d_hits.p, (unsigned long long*)nullptr);
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(hits_out, d_hits.p, (size_t)n * sizeof(HitOut), hipMemcpyDeviceToHost, c->stream));
@@ -586,7 +603,7 @@ int ptgpu_trace_batch_noalloc(ptgpu_ctx* c, const float* rays, uint32_t n, ptgpu
     HitOut* d_hits = reinterpret_cast<HitOut*>(c->scratch + kNoAllocRayBytes);
     // nothing in the scratch has to start at zero: the kernel writes every hit record in [0, n) and reads only rays [0, n)
     HIP_TRY(hipMemcpyAsync(d_rays, rays, 7 * (size_t)n * sizeof(float), hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(k_trace_batch<false>, dim3(grid_for(c, n)), dim3(kBlock), c->bvh_lds, c->stream, c->scene, d_rays, n, d_hits, (unsigned long long*)nullptr);
+    PT_LAUNCH_WALK(c, HIP_KERNEL_NAME(k_trace_batch<false>), grid_for(c, n), c->scene, d_rays, n, d_hits, (unsigned long long*)nullptr);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(hits_out, d_hits, (size_t)n * sizeof(HitOut), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -605,7 +622,7 @@ int ptgpu_occluded_batch(ptgpu_ctx* c, const float* from, const float* to, uint3
     HIP_TRY(d_out.alloc(n));
     HIP_TRY(hipMemcpyAsync(d_from.p, from, 3 * (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(d_to.p, to, 3 * (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(k_occluded_batch, dim3(grid_for(c, n)), dim3(kBlock), c->bvh_lds, c->stream, c->scene, d_from.p, d_to.p, n, d_out.p);
+    PT_LAUNCH_WALK(c, k_occluded_batch, grid_for(c, n), c->scene, d_from.p, d_to.p, n, d_out.p);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(out, d_out.p, n, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -667,13 +684,16 @@ int ptgpu_set_batch_paths(ptgpu_ctx* c, uint32_t n_paths) {
 namespace {
 
 void launch_extend(ptgpu_ctx* c, int grid, const PathCols& A, const HitCols& H, const RoundCounters* cnt) {
-    if (c->census_on) hipLaunchKernelGGL(k_extend<true>, dim3(grid), dim3(kBlock), c->bvh_lds, c->stream, c->scene, A, H, cnt, c->d_census.p);
-    else hipLaunchKernelGGL(k_extend<false>, dim3(grid), dim3(kBlock), c->bvh_lds, c->stream, c->scene, A, H, cnt, c->d_census.p);
+    if (c->census_on) PT_LAUNCH_WALK(c, HIP_KERNEL_NAME(k_extend<true>), grid, c->scene, A, H, cnt, c->d_census.p);
+    else PT_LAUNCH_WALK(c, HIP_KERNEL_NAME(k_extend<false>), grid, c->scene, A, H, cnt, c->d_census.p);
 }
 
 int upload_lambda_table(ptgpu_ctx* c, const std::vector<float>& u) {
-    HIP_TRY(c->d_lambda_u.upload(u, c->stream));
-    HIP_TRY(c->d_lambda_tab.alloc(4 * u.size()));
+    // grow-only buffers kept by the context: a render allocates nothing here once the first one of its size has run
+    HIP_TRY(c->d_lambda_u.reserve(u.size()));
+    HIP_TRY(hipMemcpyAsync(c->d_lambda_u.p, u.data(), u.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));  // `u` is the caller's temporary
+    HIP_TRY(c->d_lambda_tab.reserve(4 * u.size()));
     const uint32_t n = (uint32_t)u.size();
     hipLaunchKernelGGL(k_build_lambda_table, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, c->d_lambda_u.p, c->d_lambda_tab.p, n);
     HIP_TRY(hipGetLastError());
@@ -714,8 +734,8 @@ int run_batch_path_like(ptgpu_ctx* c, bool light, const RenderParams& rp, uint32
             hipLaunchKernelGGL(k_raygen_light, dim3(grid), dim3(kBlock), 0, c->stream, c->scene, c->camera, rp, A, S, cnt, n_paths, npix, first_sample, sample_step);
         }
         StageTimer t(c, PTGPU_STAGE_OCCLUDE);
-        if (c->census_on) hipLaunchKernelGGL(k_occlude_splat<true>, dim3(grid), dim3(kBlock), c->bvh_lds, c->stream, c->scene, rp, S, cnt, c->d_census.p);
-        else hipLaunchKernelGGL(k_occlude_splat<false>, dim3(grid), dim3(kBlock), c->bvh_lds, c->stream, c->scene, rp, S, cnt, c->d_census.p);
+        if (c->census_on) PT_LAUNCH_WALK(c, HIP_KERNEL_NAME(k_occlude_splat<true>), grid, c->scene, rp, S, cnt, c->d_census.p);
+        else PT_LAUNCH_WALK(c, HIP_KERNEL_NAME(k_occlude_splat<false>), grid, c->scene, rp, S, cnt, c->d_census.p);
     } else {
         StageTimer t(c, PTGPU_STAGE_RAYGEN);
         hipLaunchKernelGGL(k_raygen_camera, dim3(grid), dim3(kBlock), 0, c->stream, c->scene, c->camera, rp, A, cnt, n_paths, npix, first_sample, sample_step);
@@ -740,11 +760,11 @@ int run_batch_path_like(ptgpu_ctx* c, bool light, const RenderParams& rp, uint32
         {
             StageTimer t(c, PTGPU_STAGE_OCCLUDE);
             if (light) {
-                if (c->census_on) hipLaunchKernelGGL(k_occlude_splat<true>, dim3(grid), dim3(kBlock), c->bvh_lds, c->stream, c->scene, rp, S, cnt + round + 1, c->d_census.p);
-                else hipLaunchKernelGGL(k_occlude_splat<false>, dim3(grid), dim3(kBlock), c->bvh_lds, c->stream, c->scene, rp, S, cnt + round + 1, c->d_census.p);
+                if (c->census_on) PT_LAUNCH_WALK(c, HIP_KERNEL_NAME(k_occlude_splat<true>), grid, c->scene, rp, S, cnt + round + 1, c->d_census.p);
+                else PT_LAUNCH_WALK(c, HIP_KERNEL_NAME(k_occlude_splat<false>), grid, c->scene, rp, S, cnt + round + 1, c->d_census.p);
             } else {
-                if (c->census_on) hipLaunchKernelGGL(k_occlude_path<true>, dim3(grid), dim3(kBlock), c->bvh_lds, c->stream, c->scene, rp, B, S, cnt + round + 1, c->d_census.p);
-                else hipLaunchKernelGGL(k_occlude_path<false>, dim3(grid), dim3(kBlock), c->bvh_lds, c->stream, c->scene, rp, B, S, cnt + round + 1, c->d_census.p);
+                if (c->census_on) PT_LAUNCH_WALK(c, HIP_KERNEL_NAME(k_occlude_path<true>), grid, c->scene, rp, B, S, cnt + round + 1, c->d_census.p);
+                else PT_LAUNCH_WALK(c, HIP_KERNEL_NAME(k_occlude_path<false>), grid, c->scene, rp, B, S, cnt + round + 1, c->d_census.p);
             }
         }
         HIP_TRY(hipGetLastError());
@@ -754,7 +774,6 @@ int run_batch_path_like(ptgpu_ctx* c, bool light, const RenderParams& rp, uint32
             // all counters so far in one copy: the look that finds the queue empty is also the batch's statistics
             HIP_TRY(hipMemcpyAsync(c->h_counters.data(), cnt, (size_t)(round + 1) * sizeof(RoundCounters), hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(hipStreamSynchronize(c->stream));
-            if (getenv("PTGPU_DEBUG") && round > (int)rp.max_depth + 2 && round < 200) fprintf(stderr, "[ptgpu] round %d: %u paths alive\n", round, c->h_counters[round].n_active);
             if (c->h_counters[round].n_active == 0) break;
         }
     }

@@ -159,3 +159,31 @@ def furnace_scene(kind: str = "plain"):
     elif kind == "skip":
         meshes.append({"points": p * 2.5 + np.array([0, 0, 5.0], dtype=np.float32), "triangles": t, "material_index": -1})
     return pt.SceneDescription(meshes, mats)
+
+
+def deep_chain_scene(n: int, base: float):
+    """n small triangles on the space diagonal at geometrically growing distances (base^i): the SAH build peels them off a
+    few at a time, which makes the BVH as deep as the reference's 64-entry traversal stack allows (180 / 1.6 -> depth 59,
+    200 / 1.5 -> depth 64). Returns (scene, centroids, sizes)."""
+    pts, tris, cen, size = [], [], [], []
+    for i in range(n):
+        s = base ** i
+        e = 0.01 * s
+        pts += [[s, s, s], [s + e, s, s + e], [s, s + e, s]]
+        tris.append([3 * i, 3 * i + 1, 3 * i + 2])
+        cen.append([s + e / 3, s + e / 3, s + e / 3])
+        size.append(e)
+    sc = pt.SceneDescription([{"points": np.array(pts, dtype=np.float32), "triangles": np.array(tris, dtype=np.uint32), "material_index": -1}], [])
+    return sc, np.array(cen, dtype=np.float64), np.array(size, dtype=np.float64)
+
+
+def bvh_depth(nodes) -> int:
+    """Depth of the deepest node of a flattened BVH (node words as ptgpu_scene_bvh returns them)."""
+    depth, deepest = {0: 0}, 0
+    for i in range(len(nodes)):
+        d = depth[i]
+        deepest = max(deepest, d)
+        if (int(nodes[i, 7]) & 0xffff) == 0:
+            depth[i + 1] = d + 1
+            depth[int(nodes[i, 6])] = d + 1
+    return deepest

@@ -78,6 +78,35 @@ def test_empty_batch_and_misses(gpu_ctx):
     assert (h["hit"] == 0).all() and (h["t"] == 0).all()
 
 
+def test_hits_in_a_bvh_as_deep_as_the_reference_allows(gpu_ctx):
+    """A 59-level BVH: the traversal stacks need 70 KB of LDS per workgroup, more than a kernel gets without asking
+    (hipFuncAttributeMaxDynamicSharedMemorySize). Hits stay bit exact; one level beyond the reference's 64-entry stack
+    (bvh.rs:94: the reference would panic in ArrayVec::push) is refused at scene creation."""
+    sc, cen, size = su.deep_chain_scene(180, 1.6)
+    o = both(sc, gpu_ctx)
+    gn, gl = gpu_ctx.scene_bvh()
+    on, ol = o.bvh()
+    assert (gn == on).all() and (gl == ol).all()
+    assert su.bvh_depth(gn) == 59
+    rng = np.random.default_rng(3)
+    # rays at the SMALL triangles (the deepest leaves: the build peels the large ones off first), from the side, so that every
+    # coordinate the walk multiplies stays far from f32 overflow (the largest triangles sit at 1.6^179 = 4e36)
+    k = rng.integers(0, 80, 50000)
+    target = cen[k] + rng.normal(size=(len(k), 3)) * size[k, None] * 0.3
+    side = np.cross(rng.normal(size=(len(k), 3)), [1.0, 1.0, 1.0])
+    side /= np.linalg.norm(side, axis=1, keepdims=True)
+    origin = cen[k] + side * size[k, None] * rng.uniform(5.0, 50.0, (len(k), 1))
+    rays = np.concatenate([origin, target - origin, np.full((len(k), 1), np.inf)], axis=1).astype(np.float32)
+    g, c = gpu_ctx.trace(rays), o.trace(rays)
+    assert c["hit"].mean() > 0.2
+    assert_hits_bit_exact(g, c)
+    assert (gpu_ctx.occluded(origin[:2000], target[:2000]) == o.occluded(origin[:2000], target[:2000])).all()
+    too_deep, _, _ = su.deep_chain_scene(200, 1.5)
+    assert su.bvh_depth(ob.OracleScene(too_deep).bvh()[0]) == 64
+    with pytest.raises(pt.PtError, match="64-entry"):
+        gpu_ctx.set_scene(too_deep)
+
+
 @pytest.mark.parametrize("name", ["cornell-box", "veach-bidir", "veach-mis"])
 def test_hits_on_shipped_scenes(gpu_ctx, name):
     sc = pt.LoadedScene(name)
