@@ -67,3 +67,40 @@ def test_gpu_reproduces_golden_films(gpu_ctx, name, kind, mode, spp):
     ref = g[name + "_film"]
     # identical paths; device libm may differ from the host's in the last ulp of a few transcendental results
     np.testing.assert_allclose(film, ref, rtol=2e-4, atol=1e-6)
+
+
+# ------------------------------------------------------------------ converged images (BASELINE metric: "relMSE vs CPU reference")
+def _rel_terms(img, ref):
+    return ((img - ref) ** 2 / (ref ** 2 + 1e-2)).mean(axis=2).ravel()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,kind,scene", [("path", pt.INTEGRATOR_PATH, "cornell-box"), ("lightpath", pt.INTEGRATOR_LIGHTPATH, "cornell-box"),
+                                             ("guided", pt.INTEGRATOR_GUIDED, "cornell-box-guided")])
+def test_gpu_relmse_against_converged_oracle_image(gpu_ctx, name, kind, scene):
+    """north_star: "images at high spp match the reference renderer's converged images within a stated relMSE per
+    integrator". Reference = the CPU oracle at 16 384 spp (converged_cornell_64.npz, tests/golden/make_converged.py);
+    the GPU renders 1 024 spp (guided 1 023). The stated bound per integrator is the ORACLE's own relMSE at that sample
+    count against the same reference (stored beside it) — Monte Carlo noise of the reference's estimators on this scene
+    (path: 0.65, fireflies of BSDF-sampled light hits behind the glass cube; lightpath: 1.6e-4; guided: 2.0):
+      * path, lightpath: the GPU walks the oracle's very paths, so its image equals the oracle's 1 024-spp image
+        (relMSE < 1e-4 between the two) and its relMSE against the converged image equals the oracle's within 2 %;
+      * guided: a free-running render (f32 atomic order decides near-ties in the tree): the pixel-wise relMSE terms have
+        the oracle's distribution — median and 90th percentile within 25 %."""
+    g = np.load(GOLD / "converged_cornell_64.npz")
+    sc = pt.LoadedScene(scene, resx=64, resy=64, max_depth=16)
+    gpu_ctx.load(sc)
+    integ = pt.IntegratorDesc.from_buffer_copy(sc.integrator)
+    integ.kind = kind
+    film, scale, _ = gpu_ctx.render(integ, int(g[f"{name}_spp"]))
+    img, ref, own = film * scale, g[f"{name}_ref"], g[f"{name}_own"]
+    mine, oracle = _rel_terms(img, ref), _rel_terms(own, ref)
+    assert abs(oracle.mean() - float(g[f"{name}_oracle_relmse"])) < 1e-9
+    print(f"{name}: relMSE vs converged oracle: gpu {mine.mean():.6g}, oracle {oracle.mean():.6g}; median terms {np.median(mine):.4g} / {np.median(oracle):.4g}")
+    if kind != pt.INTEGRATOR_GUIDED:
+        assert _rel_terms(img, own).mean() < 1e-4
+        assert abs(mine.mean() / oracle.mean() - 1.0) < 0.02
+    else:
+        assert abs(img.mean() / own.mean() - 1.0) < 0.02
+        for q in (0.5, 0.9):
+            assert abs(np.quantile(mine, q) / np.quantile(oracle, q) - 1.0) < 0.25, (q, np.quantile(mine, q), np.quantile(oracle, q))
