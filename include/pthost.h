@@ -40,6 +40,10 @@ int pthost_rgb_to_spectrum(const float rgb[3], ptgpu_spectrum* out);
  * Writes RGBA8 PNG to <dir>/<file_name> (dir created if missing). */
 int pthost_save_image(const double* film_rgb, uint32_t resx, uint32_t resy, double scale, int as_splats, const char* dir,
                       const char* file_name);
+/* Film::save_image with both of the reference's buffers (either may be NULL = all zero): splat pixels are written with
+ * gamma 1/2.2, tile pixels are then added with gamma 1/2.4 as u8 (wrapping, as `+=` does in a release build). */
+int pthost_save_image_film(const double* tile_rgb, const double* splat_rgb, uint32_t resx, uint32_t resy, double scale, const char* dir,
+                           const char* file_name);
 /* Linear float dump (PFM, little endian, bottom-up rows as the format requires) for relMSE tooling. */
 int pthost_save_pfm(const double* film_rgb, uint32_t resx, uint32_t resy, double scale, const char* path);
 

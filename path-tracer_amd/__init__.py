@@ -93,7 +93,7 @@ PTGPU_SYMBOLS = [
 ]
 PTHOST_SYMBOLS = [
     "pthost_last_error", "pthost_scene_load", "pthost_scene_free", "pthost_scene_desc", "pthost_camera_desc",
-    "pthost_integrator_desc", "pthost_spp", "pthost_output_name", "pthost_rgb_to_spectrum", "pthost_save_image", "pthost_save_pfm",
+    "pthost_integrator_desc", "pthost_spp", "pthost_output_name", "pthost_rgb_to_spectrum", "pthost_save_image", "pthost_save_pfm", "pthost_save_image_film",
 ]
 
 _gpu = None
@@ -123,6 +123,7 @@ def load_host() -> C.CDLL:
         lib.pthost_output_name.argtypes = [C.c_void_p]
         lib.pthost_rgb_to_spectrum.argtypes = [C.POINTER(C.c_float), C.POINTER(Spectrum)]
         lib.pthost_save_image.argtypes = [C.POINTER(C.c_double), C.c_uint32, C.c_uint32, C.c_double, C.c_int, C.c_char_p, C.c_char_p]
+        lib.pthost_save_image_film.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_uint32, C.c_uint32, C.c_double, C.c_char_p, C.c_char_p]
         lib.pthost_save_pfm.argtypes = [C.POINTER(C.c_double), C.c_uint32, C.c_uint32, C.c_double, C.c_char_p]
         _host = lib
     return _host
@@ -491,3 +492,21 @@ def save_image(film, scale, as_splats, directory, file_name):
     if lib.pthost_save_image(film.ctypes.data_as(C.POINTER(C.c_double)), w, h, float(scale), 1 if as_splats else 0,
                              str(directory).encode(), file_name.encode()) != 0:
         raise PtError("save_image failed")
+
+
+def save_image_film(tile_film, splat_film, scale, directory, file_name):
+    """Film::save_image with both buffers (either may be None)."""
+    lib = load_host()
+    bufs = [None if f is None else np.ascontiguousarray(f, dtype=np.float64) for f in (tile_film, splat_film)]
+    h, w = next(b for b in bufs if b is not None).shape[:2]
+    ptrs = [None if b is None else b.ctypes.data_as(C.POINTER(C.c_double)) for b in bufs]
+    if lib.pthost_save_image_film(ptrs[0], ptrs[1], w, h, float(scale), str(directory).encode(), file_name.encode()) != 0:
+        raise PtError("save_image_film failed")
+
+
+def save_pfm(film, scale, path):
+    lib = load_host()
+    film = np.ascontiguousarray(film, dtype=np.float64)
+    h, w = film.shape[:2]
+    if lib.pthost_save_pfm(film.ctypes.data_as(C.POINTER(C.c_double)), w, h, float(scale), str(path).encode()) != 0:
+        raise PtError("save_pfm failed")

@@ -1161,22 +1161,32 @@ int pthost_rgb_to_spectrum(const float rgb[3], ptgpu_spectrum* out) {
     return guarded([&]() { return rgb_to_spectrum(rgb, out) ? 0 : -1; }, -1);
 }
 
-int pthost_save_image(const double* film, uint32_t w, uint32_t h, double scale, int as_splats, const char* dir, const char* file_name) {
-    if (!film || !dir || !file_name || w == 0 || h == 0) return -1;
-    // Film::save_image (camera.rs:197-237): gamma 1/2.2 for splats, 1/2.4 for tile pixels, *255.999 truncated.
-    const double g = as_splats ? 1.0 / 2.2 : 1.0 / 2.4;
+// Film::save_image (camera.rs:197-237), whole: the splat buffer is written first with gamma 1/2.2, then every tile pixel
+// is ADDED with gamma 1/2.4, as u8 (`+=` wraps in a release build); alpha 255; RGBA8 rows top to bottom.
+static unsigned char transfer_u8(double linear, double inv_gamma) {
+    double v = pow(linear, inv_gamma);  // NaN (negative base) -> clamp keeps NaN -> `as u8` = 0
+    v = v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v);
+    const double q = v * 255.999;
+    return (q != q) ? 0 : (unsigned char)q;
+}
+int pthost_save_image_film(const double* tile_rgb, const double* splat_rgb, uint32_t w, uint32_t h, double scale, const char* dir, const char* file_name) {
+    if (!dir || !file_name || w == 0 || h == 0) return -1;
     std::vector<unsigned char> data((size_t)w * h * 4);
     for (size_t i = 0; i < (size_t)w * h; i++) {
         for (int c = 0; c < 3; c++) {
-            double v = pow(film[3 * i + c] * scale, g);  // NaN (negative base) -> clamp keeps NaN -> `as u8` = 0
-            v = v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v);
-            const double q = v * 255.999;
-            data[4 * i + c] = (q != q) ? 0 : (unsigned char)q;
+            unsigned char v = transfer_u8((splat_rgb ? splat_rgb[3 * i + c] : 0.0) * scale, 1.0 / 2.2);
+            v = (unsigned char)(v + transfer_u8((tile_rgb ? tile_rgb[3 * i + c] : 0.0) * scale, 1.0 / 2.4));  // u8 += u8, wrapping
+            data[4 * i + c] = v;
         }
         data[4 * i + 3] = 255;
     }
     mkdir(dir, 0777);
     return write_png_rgba(std::string(dir) + "/" + file_name, data, w, h) ? 0 : -1;
+}
+// One film from ptgpu_render: lightpath fills only the splat buffer, path and guided only the tiles.
+int pthost_save_image(const double* film, uint32_t w, uint32_t h, double scale, int as_splats, const char* dir, const char* file_name) {
+    if (!film) return -1;
+    return as_splats ? pthost_save_image_film(nullptr, film, w, h, scale, dir, file_name) : pthost_save_image_film(film, nullptr, w, h, scale, dir, file_name);
 }
 
 int pthost_save_pfm(const double* film, uint32_t w, uint32_t h, double scale, const char* path) {

@@ -473,3 +473,32 @@ def test_bench_rccl_path_rehearsal(workload):
     assert len(lines) == 1, lines  # ONE JSON line on stdout: RCCL's banner and the like go to stderr
     line = json.loads(lines[0])
     assert line["n_gpus"] == 1 and line["value"] > 0 and line["roofline"]["achieved"] > 0
+
+
+# ------------------------------------------------------------------ the `pt` executable (main.rs:25-51) end to end
+@pytest.mark.parametrize("integrator", ["path", "lightpath"])
+def test_pt_cli_writes_the_film_the_abi_returns(gpu_ctx, tmp_path, integrator):
+    """`pt cornell-box` in a child process: parse -> render through the C ABI -> zout/<output>.png with Film::save_image's
+    transfer (gamma 1/2.4 for path, 1/2.2 for lightpath's splats). The PNG must decode to the bytes the numpy restatement
+    of camera.rs:197-237 makes of the film ptgpu_render returns for the same scene in this process."""
+    import subprocess
+    from PIL import Image
+    from test_host_cpu import reference_png_bytes
+    repo = Path(__file__).resolve().parent.parent
+    r = subprocess.run([str(repo / "path-tracer_amd" / "lib" / "pt"), "--scenes", str(repo / "scenes"), "--spp", "4", "--resx", "32", "--resy", "32",
+                        "--integrator", integrator, "--pfm", "cornell-box"], cwd=tmp_path, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert 'output_name = "test1.png"' in r.stderr                       # dbg!(elapsed, output_name) of main.rs:42-44
+    png = np.array(Image.open(tmp_path / "zout" / "test1.png"))
+    sc = pt.LoadedScene("cornell-box", resx=32, resy=32, spp=4, integrator=integrator)
+    assert sc.output_name == "test1.png"
+    gpu_ctx.load(sc)
+    film, scale, _ = gpu_ctx.render(sc.integrator, sc.spp)
+    light = integrator == "lightpath"
+    want = reference_png_bytes(None if light else film, film if light else None, scale)
+    assert png.shape == want.shape == (32, 32, 4)
+    # f64 atomic adds land in another order in the other process: a byte may sit on a truncation step
+    assert (png != want).sum() <= 4 and np.abs(png.astype(int) - want.astype(int)).max() <= 1
+    raw = (tmp_path / "zout" / "test1.png.pfm").read_bytes().split(b"\n", 3)
+    pfm = np.frombuffer(raw[3], dtype="<f4").reshape(32, 32, 3)[::-1]
+    assert np.allclose(pfm, film * scale, rtol=1e-5, atol=1e-7)
