@@ -9,13 +9,27 @@ namespace pt {
 // Build with -DPT_DBG_TIMING to attribute k_shade_guided's wave time to its sections (s_memtime deltas summed over
 // all waves into g_dbg_cycles; ptgpu_guided_end prints them). Compiled out otherwise.
 #ifdef PT_DBG_TIMING
-__device__ unsigned long long g_dbg_cycles[16];
-#define PT_TICK_INIT() long long dbg_last = clock64(); long long dbg_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
-#define PT_TICK(k) do { const long long now_ = clock64(); dbg_acc[k] += now_ - dbg_last; dbg_last = now_; } while (0)
-#define PT_TICK_FLUSH() do { for (int k_ = 0; k_ < 12; k_++) { long long v_ = dbg_acc[k_]; for (int o_ = 32; o_ > 0; o_ >>= 1) { const long long w_ = __shfl_xor(v_, o_); v_ = w_ > v_ ? w_ : v_; } \
-        if (__lane_id() == 0) atomicAdd(&g_dbg_cycles[k_], (unsigned long long)v_); } } while (0)
-#define PT_DBG_PARAMS , long long& dbg_last, long long* dbg_acc
-#define PT_DBG_ARGS , dbg_last, dbg_acc
+// Wave-level accounting: the time since the wave's previous tick (whichever lanes took it) goes to section k, once as
+// cycles and once weighted by the lanes active at the tick. Kept in LDS per wave by the first active lane, so ticks
+// inside divergent code are charged in the order the wave really executes them.
+constexpr int kDbgSections = 24;
+__device__ unsigned long long g_dbg_cycles[2 * kDbgSections];
+PT_D void dbg_tick(unsigned long long* w, int k) {
+    const unsigned long long now = (unsigned long long)clock64();
+    const unsigned long long ex = __ballot(true);
+    if ((int)__lane_id() == __ffsll((long long)ex) - 1) {
+        const unsigned long long dt = now - w[0];
+        w[0] = now;
+        w[1 + k] += dt;
+        w[1 + kDbgSections + k] += dt * (unsigned long long)__popcll(ex);
+    }
+}
+#define PT_TICK_INIT() __shared__ unsigned long long sm_dbg[4 * (1 + 2 * kDbgSections)]; unsigned long long* dbg_w = sm_dbg + (threadIdx.x / 64u) * (1 + 2 * kDbgSections); \
+    if (__lane_id() == 0) { for (int k_ = 1; k_ < 1 + 2 * kDbgSections; k_++) dbg_w[k_] = 0; dbg_w[0] = (unsigned long long)clock64(); }
+#define PT_TICK(k) dbg_tick(dbg_w, k)
+#define PT_TICK_FLUSH() do { if (__lane_id() == 0) for (int k_ = 0; k_ < 2 * kDbgSections; k_++) if (dbg_w[1 + k_]) atomicAdd(&g_dbg_cycles[k_], dbg_w[1 + k_]); } while (0)
+#define PT_DBG_PARAMS , unsigned long long* dbg_w
+#define PT_DBG_ARGS , dbg_w
 #else
 #define PT_DBG_PARAMS
 #define PT_DBG_ARGS
@@ -330,10 +344,12 @@ PT_D bool guider_sample(const SdTreeDev& t, const Bsdf& bsdf, const Frame& fr, V
                         BsdfSample& s PT_DBG_PARAMS) {
     if (t.iteration == 0 || bsdf_is_specular(bsdf)) {
         const float u1d = rng_f32(rng), ua = rng_f32(rng), ub = rng_f32(rng);
-        return bsdf_sample(bsdf, fr, ng, wo, u1d, ua, ub, true, s);
+        const bool ok = bsdf_sample(bsdf, fr, ng, wo, u1d, ua, ub, true, s);
+        PT_TICK(14);
+        return ok;
     }
     const uint4 leaf = make_uint4(sampler_word & 0x7fffffffu, 0u, sampler_word >> 31, 0u);  // leaf_info's x and z
-    PT_TICK(3);
+    PT_TICK(15);
     // Both branches need the tree's pdf at the chosen direction: one quadtree descent per wave serves the lanes
     // that sample from the tree and the lanes that only evaluate it (dtree_walk). Values are unchanged.
     const bool use_tree = rng_f32(rng) < 0.5f;
@@ -344,7 +360,7 @@ PT_D bool guider_sample(const SdTreeDev& t, const Bsdf& bsdf, const Frame& fr, V
         sq = dir_to_square(s.wi);
         PT_TICK(5);
     }
-    PT_TICK(4);
+    PT_TICK(16);
     const float tree_pdf = dtree_walk(t, leaf, use_tree, rng, sq, lds_scales, root);
     PT_TICK(6);
     if (use_tree) {
@@ -359,7 +375,7 @@ PT_D bool guider_sample(const SdTreeDev& t, const Bsdf& bsdf, const Frame& fr, V
     } else {
         s.pdf = 0.5f * s.pdf + 0.5f * tree_pdf;
     }
-    PT_TICK(7);
+    PT_TICK(17);
     return true;
 }
 
@@ -605,18 +621,20 @@ PT_D void store_vertex(const GuidedParams& gp, uint32_t row, uint32_t pid, V3 p,
 // One iteration of PathGuidingIntegrator::random_walk's loop body (mod.rs:139-278).
 template <int KINDS>
 __global__ __launch_bounds__(kBlock, KINDS != 7 ? PT_GUIDED_DIFFUSE_WAVES : PT_SHADE_WAVES) void k_shade_guided(SceneDev sc, SdTreeDev tree, RenderParams rp, GuidedParams gp, PathCols in, HitCols hit, PathCols out,
-                                                         ShadowCols sh, const RoundCounters* cur, RoundCounters* nxt) {
-    __shared__ BlockAlloc sm_alloc;
+                                                         ShadowCols sh, const RoundCounters* cur, RoundCounters* nxt, const uint32_t* cur_top, uint32_t* nxt_top) {
+    __shared__ BlockAlloc3 sm_alloc;
     __shared__ uint32_t sm_count;
     __shared__ float sm_scales[(kMaxQuadLevel + 1) * kBlock];
     PT_TICK_INIT();
     uint32_t n_shaded = 0, n_skipped = 0;
-    const uint32_t n = cur->n_active;
+    const uint32_t n_bottom = cur->n_active;
+    const uint32_t n = n_bottom + *cur_top;
     const uint32_t stride = gridDim.x * blockDim.x;
     const uint32_t n_iter = (n + stride - 1) / stride;
     for (uint32_t it = 0; it < n_iter; it++) {
-        const uint32_t i = it * stride + blockIdx.x * blockDim.x + threadIdx.x;
-        const bool valid = i < n;
+        const uint32_t j = it * stride + blockIdx.x * blockDim.x + threadIdx.x;
+        const bool valid = j < n;
+        const uint32_t i = slot_of_index(j, n_bottom, rp.capacity);
         bool alive = false, want_shadow = false, shaded = false, skipped_shadow = false, ended = false;
         V3 o = mk3(0, 0, 0), d = mk3(0, 0, 1), sh_from = mk3(0, 0, 0), sh_to = mk3(0, 0, 0);
         uint32_t flags = 0, pid = 0, nverts = 0, shadow_row = 0;
@@ -642,6 +660,7 @@ __global__ __launch_bounds__(kBlock, KINDS != 7 ? PT_GUIDED_DIFFUSE_WAVES : PT_S
                 } else
                     atomicAdd(sc.guards + kGuardVertexStore, 1u);
                 ended = true;
+                PT_TICK(12);
             } else {
                 const float4 tb = hit.tb[i];
                 beta = load_spec(in.beta0, in.beta1, i);
@@ -699,6 +718,7 @@ __global__ __launch_bounds__(kBlock, KINDS != 7 ? PT_GUIDED_DIFFUSE_WAVES : PT_S
                     }
                     Spec le = spec_splat(0.0f);
                     if (have_light) le = spec_lookup(rp.spec, rp.spec.emission_base + lt.mesh, row);
+                    PT_TICK(13);
                     uint32_t sampler_word = 0x80000000u;
                     SNode root;
                     root.rad = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -743,6 +763,7 @@ __global__ __launch_bounds__(kBlock, KINDS != 7 ? PT_GUIDED_DIFFUSE_WAVES : PT_S
                         ended = true;
                     } else {
                         flags = specular ? (flags | FLAG_SPECULAR_BOUNCE) : (flags & ~FLAG_SPECULAR_BOUNCE);
+                        if (specular && dot(bs.wi, sf.ng) * dot(wo, sf.ng) < 0.0f) flags ^= FLAG_INSIDE;  // went through the surface (queueing hint only)
                         Spec fw;
 #pragma unroll
                         for (int k = 0; k < NSW; k++) fw.v[k] = bs.f.v[k] / bs.pdf;
@@ -767,13 +788,15 @@ __global__ __launch_bounds__(kBlock, KINDS != 7 ? PT_GUIDED_DIFFUSE_WAVES : PT_S
                             ended = !alive;
                         }
                     }
+                    PT_TICK(18);
                 }
             }
             rp4.w = (rp4.w & 0xffffu) | (nverts << 16);
         }
         PT_TICK(8);
         uint32_t a_slot, s_slot;
-        block_alloc2(sm_alloc, nxt, alive, want_shadow, a_slot, s_slot);
+        const bool to_top = alive && (flags & FLAG_INSIDE) != 0;  // the next surface is, in all likelihood, the body's own: specular
+        block_alloc3(sm_alloc, nxt, nxt_top, rp.capacity, alive && !to_top, to_top, want_shadow, a_slot, s_slot);
         PT_TICK(9);
         n_shaded += shaded ? 1u : 0u;
         n_skipped += skipped_shadow ? 1u : 0u;

@@ -63,6 +63,43 @@ PT_D void block_alloc2(BlockAlloc& sm, RoundCounters* rc, bool want_a, bool want
     slot_a = sm.base[0] + wa + (uint32_t)__popcll(ma & below);
     slot_b = sm.base[1] + wb + (uint32_t)__popcll(mb & below);
 }
+// block_alloc2 with the survivors in two classes: `want_a` lanes take slots from the bottom of the state set
+// (rc->n_active), `want_t` lanes from the top (*top, a counter on a cache line of its own: the two atomics are in flight
+// together and do not queue behind one another at the memory side); `want_b` lanes take shadow-queue slots as before.
+struct BlockAlloc3 {
+    uint32_t cnt[3];
+    uint32_t base[3];
+};
+PT_D void block_alloc3(BlockAlloc3& sm, RoundCounters* rc, uint32_t* top, uint32_t capacity, bool want_a, bool want_t, bool want_b, uint32_t& slot_a, uint32_t& slot_b) {
+    if (threadIdx.x == 0) sm.cnt[0] = sm.cnt[1] = sm.cnt[2] = 0;
+    lds_barrier();
+    const uint32_t lane = __lane_id();
+    const unsigned long long ma = __ballot(want_a), mt = __ballot(want_t), mb = __ballot(want_b);
+    uint32_t wa = 0, wt = 0, wb = 0;
+    if (lane == 0) {
+        if (ma) wa = atomicAdd(&sm.cnt[0], (uint32_t)__popcll(ma));
+        if (mt) wt = atomicAdd(&sm.cnt[1], (uint32_t)__popcll(mt));
+        if (mb) wb = atomicAdd(&sm.cnt[2], (uint32_t)__popcll(mb));
+    }
+    wa = __shfl(wa, 0);
+    wt = __shfl(wt, 0);
+    wb = __shfl(wb, 0);
+    lds_barrier();
+    if (threadIdx.x == 0) {
+        const unsigned long long add = (unsigned long long)sm.cnt[0] | ((unsigned long long)sm.cnt[2] << 32);
+        unsigned long long old = 0;
+        uint32_t old_t = 0;
+        if (add) old = atomicAdd(reinterpret_cast<unsigned long long*>(&rc->n_active), add);
+        if (sm.cnt[1]) old_t = atomicAdd(top, sm.cnt[1]);
+        sm.base[0] = (uint32_t)old;
+        sm.base[2] = (uint32_t)(old >> 32);
+        sm.base[1] = old_t;
+    }
+    lds_barrier();
+    const unsigned long long below = (1ull << lane) - 1ull;
+    slot_a = want_t ? capacity - 1u - (sm.base[1] + wt + (uint32_t)__popcll(mt & below)) : sm.base[0] + wa + (uint32_t)__popcll(ma & below);
+    slot_b = sm.base[2] + wb + (uint32_t)__popcll(mb & below);
+}
 // Sum of a per-thread count over the block, added to *counter once (call after the loop, by every thread).
 PT_D void block_count_flush(uint32_t* sm_word, uint32_t* counter, uint32_t mine) {
     if (threadIdx.x == 0) *sm_word = 0;
@@ -237,13 +274,17 @@ __global__ __launch_bounds__(kBlock) void k_raygen_camera(SceneDev sc, CameraDev
 // ------------------------------------------------------------------ extend (closest hit)
 // Scene::intersect -> Bvh::intersect (scene.rs:184-186, bvh.rs:86-142) for slots [0, n_active).
 template <bool CENSUS>
-__global__ __launch_bounds__(kBlock, 8) void k_extend(SceneDev sc, PathCols st, HitCols hit, const RoundCounters* cnt, unsigned long long* census) {
-    const uint32_t n = cnt->n_active;
+// `top` (may be null) counts the entries queued from the top of the state set (slot_of_index).
+__global__ __launch_bounds__(kBlock, 8) void k_extend(SceneDev sc, PathCols st, HitCols hit, const RoundCounters* cnt, unsigned long long* census, const uint32_t* top,
+                                                      uint32_t capacity) {
+    const uint32_t n_bottom = cnt->n_active;
+    const uint32_t n = n_bottom + (top ? *top : 0u);
     if (blockIdx.x * blockDim.x >= n) return;  // late rounds: most workgroups have nothing to do, not even staging nodes
     bvh_stage_nodes(sc);
     const uint32_t stride = gridDim.x * blockDim.x;
     uint32_t cn = 0, ct = 0;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) {
+        const uint32_t i = slot_of_index(j, n_bottom, capacity);
         float4 o = st.o_pdf[i], d = st.d_flags[i];
         asm volatile("" : "+v"(o.x), "+v"(o.y), "+v"(o.z), "+v"(d.x), "+v"(d.y), "+v"(d.z));  // one load each (see bvh_intersect)
         const Hit h = bvh_intersect<CENSUS>(sc, mk3(o.x, o.y, o.z), mk3(d.x, d.y, d.z), f_inf(), &cn, &ct);

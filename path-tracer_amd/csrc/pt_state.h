@@ -22,6 +22,10 @@ constexpr uint32_t FLAG_SECONDARY_TERMINATED = 1u << 17;
 constexpr uint32_t FLAG_PASS_SHIFT = 18;
 constexpr uint32_t FLAG_PASS_MASK = 0xfffu << FLAG_PASS_SHIFT;
 constexpr uint32_t kMaxPassThrough = 256;
+// The path is inside a dielectric body (toggled by every specular transmission). Used ONLY to decide where a surviving
+// path is queued — predicted-specular survivors fill the state set from the top, the others from the bottom
+// (slot_of_index) — so that the lanes of a wave run the same material code; no result depends on it.
+constexpr uint32_t FLAG_INSIDE = 1u << 30;
 PT_HD bool passthrough_step(uint32_t& flags) {
     const uint32_t n = ((flags & FLAG_PASS_MASK) >> FLAG_PASS_SHIFT) + 1;
     flags = (flags & ~FLAG_PASS_MASK) | (n << FLAG_PASS_SHIFT);
@@ -65,6 +69,9 @@ struct RoundCounters {
     uint32_t n_active, n_shadow, n_terminal, n_segments;
 };
 constexpr int kMaxRounds = 1 << 16;
+// Dense index j of a round's queue -> slot of the state set: the first n_bottom entries sit at the bottom, the rest
+// count down from the top (capacity - 1, capacity - 2, ...).
+PT_HD uint32_t slot_of_index(uint32_t j, uint32_t n_bottom, uint32_t capacity) { return j < n_bottom ? j : capacity - 1u - (j - n_bottom); }
 
 // Guided integrator: per-path vertex store (PathVertex, path_guiding/mod.rs:281-289). One vertex = one 128-byte
 // line of eight float4 {p.xyz|wi_pdf, wi.xyz|-, f/pdf (2), emitted (2), li_sample_contribution (2)}, the rows of a

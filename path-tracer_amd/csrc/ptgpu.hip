@@ -135,6 +135,8 @@ struct ptgpu_ctx {
     DevBuf<uint2> d_hit_prim;
     DevBuf<float4> d_shadow;  // q0 | q1 | q2,q3 contiguous (4 * capacity)
     DevBuf<RoundCounters> d_counters;
+    DevBuf<uint32_t> d_top_counters;  // per round: entries queued from the top of the state set (guided: predicted-specular survivors)
+    std::vector<uint32_t> h_top_counters;
     DevBuf<double> d_film;         // kFilmStride doubles per pixel, film_copies films back to back
     uint32_t film_copies = 1;
     DevBuf<double> d_film_packed;  // RGB, what the ABI returns
@@ -214,6 +216,8 @@ int ensure_workspace(ptgpu_ctx* c, uint32_t cap) {
     HIP_TRY(c->d_shadow.alloc(4 * (size_t)cap));
     HIP_TRY(c->d_counters.alloc(kMaxRounds + 2));
     c->h_counters.resize(kMaxRounds + 2);
+    HIP_TRY(c->d_top_counters.alloc(kMaxRounds + 2));
+    c->h_top_counters.assign(kMaxRounds + 2, 0u);
     c->capacity = cap;
     return PTGPU_OK;
 }
@@ -683,9 +687,9 @@ int ptgpu_set_batch_paths(ptgpu_ctx* c, uint32_t n_paths) {
 
 namespace {
 
-void launch_extend(ptgpu_ctx* c, int grid, const PathCols& A, const HitCols& H, const RoundCounters* cnt) {
-    if (c->census_on) PT_LAUNCH_WALK(c, HIP_KERNEL_NAME(k_extend<true>), grid, c->scene, A, H, cnt, c->d_census.p);
-    else PT_LAUNCH_WALK(c, HIP_KERNEL_NAME(k_extend<false>), grid, c->scene, A, H, cnt, c->d_census.p);
+void launch_extend(ptgpu_ctx* c, int grid, const PathCols& A, const HitCols& H, const RoundCounters* cnt, const uint32_t* top = nullptr) {
+    if (c->census_on) PT_LAUNCH_WALK(c, HIP_KERNEL_NAME(k_extend<true>), grid, c->scene, A, H, cnt, c->d_census.p, top, c->capacity);
+    else PT_LAUNCH_WALK(c, HIP_KERNEL_NAME(k_extend<false>), grid, c->scene, A, H, cnt, c->d_census.p, top, c->capacity);
 }
 
 int upload_lambda_table(ptgpu_ctx* c, const std::vector<float>& u) {
