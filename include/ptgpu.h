@@ -230,6 +230,14 @@ int ptgpu_census(ptgpu_ctx* ctx, uint64_t out[4]);
  * split because they sit at level 24 (the reference has no depth cap, dtree.rs:291-324), out[3] = samples dropped
  * because their radiance was not finite (the reference asserts, path_tracer.rs:46, or poisons the pixel). */
 int ptgpu_guard_counts(ptgpu_ctx* ctx, uint64_t out[4]);
+/* Traversal of the scene's BVH (reference: Bvh::intersect, bvh.rs:86-142). 0 = the reference's binary tree,
+ * node by node; 1 = a four-wide image of the SAME tree (every wide node holds up to four descendants of one binary
+ * node; leaves, triangle order and the per-octant visit order are the binary tree's), which reports the same hits bit
+ * for bit at a quarter of the loop trips. Fails with PTGPU_E_LIMIT for a scene whose tree has no wide image (a leaf
+ * of more than 128 triangles). Takes effect from the next call on; ptgpu_scene_create resets it to the default:
+ * wide for trees of more than 1 MB of binary nodes, where it is faster (PTGPU_BVH_WIDE=0|1 in the environment overrides). ptgpu_get_traversal returns the mode in use. */
+int ptgpu_set_traversal(ptgpu_ctx* ctx, int wide);
+int ptgpu_get_traversal(ptgpu_ctx* ctx);
 /* Paths kept in flight per batch (state SoA size); 0 restores the default. */
 int ptgpu_set_batch_paths(ptgpu_ctx* ctx, uint32_t n_paths);
 

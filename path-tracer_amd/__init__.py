@@ -89,7 +89,8 @@ PTGPU_SYMBOLS = [
     "ptgpu_trace_batch", "ptgpu_occluded_batch", "ptgpu_scene_info", "ptgpu_scene_bvh", "ptgpu_set_profiling",
     "ptgpu_set_batch_paths", "ptgpu_kernel_times", "ptgpu_set_census", "ptgpu_census", "ptgpu_guided_selfcheck",
     "ptgpu_trace_batch_noalloc", "ptgpu_guided_tree_info", "ptgpu_guided_tree_download", "ptgpu_guided_probe",
-    "ptgpu_guided_record_batch", "ptgpu_guided_refine", "ptgpu_guard_counts", "ptgpu_film_device",
+    "ptgpu_guided_record_batch", "ptgpu_guided_refine", "ptgpu_guard_counts", "ptgpu_film_device", "ptgpu_set_traversal",
+    "ptgpu_get_traversal",
 ]
 PTHOST_SYMBOLS = [
     "pthost_last_error", "pthost_scene_load", "pthost_scene_free", "pthost_scene_desc", "pthost_camera_desc",
@@ -327,6 +328,15 @@ class Context:
 
     def set_batch_paths(self, n: int):
         self._check(self.lib.ptgpu_set_batch_paths(self.handle, n))
+
+    def set_traversal(self, wide: bool):
+        """0 = the reference's binary BVH walk, 1 = the four-wide image of the same tree (same hits)."""
+        self.lib.ptgpu_set_traversal.argtypes = [C.c_void_p, C.c_int]
+        self._check(self.lib.ptgpu_set_traversal(self.handle, 1 if wide else 0))
+
+    def traversal(self) -> int:
+        self.lib.ptgpu_get_traversal.argtypes = [C.c_void_p]
+        return int(self.lib.ptgpu_get_traversal(self.handle))
 
     def set_census(self, on: bool):
         self._check(self.lib.ptgpu_set_census(self.handle, 1 if on else 0))

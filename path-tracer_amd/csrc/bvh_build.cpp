@@ -121,6 +121,97 @@ struct Builder {
 
 }  // namespace
 
+namespace {
+struct WideBuilder {
+    const FlatBvh& b;
+    std::vector<WideNode>& out;
+    bool ok = true;
+    uint32_t depth = 0;
+
+    bool leaf_ref(uint32_t node, uint32_t& ref) const {
+        const FlatNode& n = b.nodes[node];
+        if (n.n_tris == 0 || n.n_tris > 128 || n.offset >= (1u << 24)) return false;
+        ref = 0x80000000u | ((uint32_t)(n.n_tris - 1) << 24) | n.offset;
+        return true;
+    }
+    // visit order of the frontier under `node` for one octant, as the binary walk would produce it
+    void order_of(uint32_t node, uint32_t octant, const std::vector<uint32_t>& frontier, std::vector<uint32_t>& seq) const {
+        for (size_t s = 0; s < frontier.size(); s++)
+            if (frontier[s] == node) {
+                seq.push_back((uint32_t)s);
+                return;
+            }
+        const FlatNode& n = b.nodes[node];
+        const bool neg = ((octant >> n.split_axis) & 1u) != 0u;
+        order_of(neg ? n.offset : node + 1, octant, frontier, seq);
+        order_of(neg ? node + 1 : n.offset, octant, frontier, seq);
+    }
+    uint32_t collapse(uint32_t node, uint32_t level) {
+        const uint32_t index = (uint32_t)out.size();
+        out.push_back(WideNode{});
+        depth = std::max(depth, level);
+        std::vector<uint32_t> frontier;
+        if (b.nodes[node].n_tris != 0) frontier = {node};  // a tree that is one leaf
+        else {
+            frontier = {node + 1, b.nodes[node].offset};
+            while (frontier.size() < 4) {
+                int pick = -1;
+                float best = -1.0f;
+                for (size_t s = 0; s < frontier.size(); s++) {
+                    const FlatNode& n = b.nodes[frontier[s]];
+                    if (n.n_tris != 0) continue;
+                    const float a = box_area(n.bounds);
+                    if (a > best) {
+                        best = a;
+                        pick = (int)s;
+                    }
+                }
+                if (pick < 0) break;
+                const uint32_t x = frontier[pick];
+                frontier[pick] = x + 1;
+                frontier.insert(frontier.begin() + pick + 1, b.nodes[x].offset);
+            }
+        }
+        WideNode w{};
+        w.n_children = (uint32_t)frontier.size();
+        for (int c = 0; c < 4; c++)
+            for (int a = 0; a < 3; a++) {
+                w.lo[a][c] = f_inf();
+                w.hi[a][c] = -f_inf();
+            }
+        for (uint32_t octant = 0; octant < 8; octant++) {
+            std::vector<uint32_t> seq;
+            order_of(node, octant, frontier, seq);
+            uint32_t byte = 0;
+            for (size_t k = 0; k < seq.size(); k++) byte |= seq[k] << (2 * k);
+            w.order[octant / 4] |= byte << (8 * (octant % 4));
+        }
+        for (size_t s = 0; s < frontier.size(); s++) {
+            const FlatNode& n = b.nodes[frontier[s]];
+            for (int a = 0; a < 3; a++) {
+                w.lo[a][s] = get(n.bounds.lo, a);
+                w.hi[a][s] = get(n.bounds.hi, a);
+            }
+            if (n.n_tris != 0) {
+                if (!leaf_ref(frontier[s], w.ref[s])) ok = false;
+            } else
+                w.ref[s] = collapse(frontier[s], level + 1);
+        }
+        out[index] = w;
+        return index;
+    }
+};
+}  // namespace
+
+bool build_wide(const FlatBvh& bvh, std::vector<WideNode>& out, uint32_t& depth_out) {
+    out.clear();
+    if (bvh.nodes.empty()) return false;
+    WideBuilder wb{bvh, out};
+    wb.collapse(0, 1);
+    depth_out = wb.depth;
+    return wb.ok && out.size() < (1u << 31);
+}
+
 bool build_bvh(std::vector<BuildTri>& tris, FlatBvh& out) {
     out.nodes.clear();
     out.leaf_order.clear();

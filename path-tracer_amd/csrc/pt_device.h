@@ -364,16 +364,138 @@ struct Hit {
 // Cornell box: TCP_TOTAL_CACHE_ACCESSES ~0.86 per cycle per CU, TA busy 82 %), two per visited node plus three per
 // tested triangle. LDS is a second, independent pipe: nodes from LDS, triangles from L1. Every kernel that walks the
 // BVH calls this first (all threads).
+template <bool WIDE = false>
 PT_D void bvh_stage_nodes(const SceneDev& sc) {
     extern __shared__ uint32_t sm_bvh_stack[];
-    if (sc.lds_nodes) {
+    if (WIDE) {
+        if (sc.lds_wnodes) {
+            float4* dst = reinterpret_cast<float4*>(sm_bvh_stack + (sc.wide_stack + kLeafQueue) * kBlock);
+            for (uint32_t i = threadIdx.x; i < 8 * sc.n_wnodes; i += kBlock) dst[i] = sc.wnodes[i];
+            __syncthreads();
+        }
+    } else if (sc.lds_nodes) {
         float4* dst = reinterpret_cast<float4*>(sm_bvh_stack + (sc.bvh_stack + 2 * kLeafQueue) * kBlock);
         for (uint32_t i = threadIdx.x; i < 2 * sc.n_nodes; i += kBlock) dst[i] = sc.nodes[i];
         __syncthreads();
     }
 }
-template <bool COUNT, bool ANY_HIT = false>
+// The triangles of one leaf against the ray, in leaf order (shared by the binary and the wide walk). Returns true when
+// an occlusion query is decided.
+template <bool COUNT, bool ANY_HIT>
+PT_D bool bvh_test_leaf(const SceneDev& sc, V3 o, const RayShear& shear, float ray_end_t, uint32_t leaf_first, uint32_t leaf_n, Hit& best, uint32_t* n_tris_tested) {
+    for (uint32_t k = leaf_first; k < leaf_first + leaf_n; k++) {
+        float4 a = sc.tri_v[3 * k], b = sc.tri_v[3 * k + 1], c = sc.tri_v[3 * k + 2];
+        // Left alone, the compiler re-loads overlapping halves of each vertex (x,y and y,z, for its packed-math
+        // pairings): six vector-memory instructions per triangle instead of three, and vector-memory issue is
+        // what bounds this loop. Passing the loaded values through an empty asm pins one 16-byte load each.
+        // (Closest-hit walks only: the occlusion kernels carry more state and would drop to 7 waves per SIMD.)
+        if (!ANY_HIT) asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(b.x), "+v"(b.y), "+v"(b.z), "+v"(c.x), "+v"(c.y), "+v"(c.z));
+        if (COUNT) (*n_tris_tested)++;
+        TriHit th;
+        if (ray_triangle(o, shear, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), best.th.t, th)) {
+            best.th = th;
+            best.prim = k;
+            if (ANY_HIT && th.t < 0.999f * ray_end_t) return true;
+        }
+    }
+    return false;
+}
+// The wide walk (bvh_build.h: WideNode): the same leaves in the same order as the binary walk below, a quarter of the
+// loop trips. Per visited node: four slab tests (against the ORIGINAL ray_end_t, as the reference tests every box,
+// plus the dominant-axis cull, which only ever skips what the reference would reject), then the children that passed
+// go onto the LDS stack in reverse visit order — the visit order of a node's children depends on the ray's direction
+// signs only and comes out of the node's table. Why skipping the collapsed inner nodes' box tests changes nothing: the
+// reference reaches a node only through its ancestors' boxes, an ancestor's box contains the node's box exactly (a join
+// of the same triangle bounds), and the slab test is monotone in the box (the products inv * (near - o) and
+// slack * inv * (far - o) are monotone in near and far for a fixed ray, a NaN from 0 * inf is ignored by fmaxf/fminf
+// exactly where the larger box gives -inf/+inf or NaN as well): a ray that passes the node's test passes every ancestor's.
+template <bool COUNT, bool ANY_HIT>
+PT_D Hit bvh_intersect_wide(const SceneDev& sc, V3 o, V3 d, float ray_end_t, uint32_t* n_nodes_visited, uint32_t* n_tris_tested) {
+    extern __shared__ uint32_t sm_bvh_stack[];
+    uint32_t* stack = sm_bvh_stack + threadIdx.x;
+    Hit best;
+    best.prim = kNoHit;
+    best.tag = 0;
+    best.th.t = ray_end_t;
+    best.th.b0 = best.th.b1 = best.th.b2 = 0.0f;
+    const V3 inv = splat(1.0f) / d;
+    const bool nx = inv.x < 0.0f, ny = inv.y < 0.0f, nz = inv.z < 0.0f;
+    const uint32_t octant = (nx ? 1u : 0u) | (ny ? 2u : 0u) | (nz ? 4u : 0u);
+    const float slack = 1.0f + 2.0f * gamma_n(3.0f);
+    const float kCullSlack = 1.0f + 0x1p-19f;
+    const V3 sinv = mk3(slack * inv.x, slack * inv.y, slack * inv.z);
+    const RayShear shear = ray_shear(d);
+    uint32_t* pend = sm_bvh_stack + sc.wide_stack * kBlock + threadIdx.x;
+    const float4* nodes = sc.lds_wnodes ? reinterpret_cast<const float4*>(sm_bvh_stack + (sc.wide_stack + kLeafQueue) * kBlock) : sc.wnodes;
+    uint32_t sp = 0;
+    uint32_t cur = 0;  // reference of the node or leaf to visit next (the root is wide node 0)
+    bool have = true;
+    for (;;) {
+        uint32_t n_pend = 0;
+        while (have && n_pend < kLeafQueue) {
+            if (cur & 0x80000000u) {
+                pend[n_pend * kBlock] = cur;
+                n_pend++;
+            } else {
+                const float4* wn = nodes + 8 * (size_t)cur;
+                const float4 lox = wn[0], loy = wn[1], loz = wn[2], hix = wn[3], hiy = wn[4], hiz = wn[5];
+                const float4 refs_f = wn[6], meta_f = wn[7];
+                const uint32_t refs[4] = {f2u(refs_f.x), f2u(refs_f.y), f2u(refs_f.z), f2u(refs_f.w)};
+                const uint32_t table = octant < 4u ? f2u(meta_f.x) : f2u(meta_f.y);
+                const uint32_t perm = (table >> (8u * (octant & 3u))) & 0xffu, n_children = f2u(meta_f.z);
+                const float nearx[4] = {nx ? hix.x : lox.x, nx ? hix.y : lox.y, nx ? hix.z : lox.z, nx ? hix.w : lox.w};
+                const float farx[4] = {nx ? lox.x : hix.x, nx ? lox.y : hix.y, nx ? lox.z : hix.z, nx ? lox.w : hix.w};
+                const float neary[4] = {ny ? hiy.x : loy.x, ny ? hiy.y : loy.y, ny ? hiy.z : loy.z, ny ? hiy.w : loy.w};
+                const float fary[4] = {ny ? loy.x : hiy.x, ny ? loy.y : hiy.y, ny ? loy.z : hiy.z, ny ? loy.w : hiy.w};
+                const float nearz[4] = {nz ? hiz.x : loz.x, nz ? hiz.y : loz.y, nz ? hiz.z : loz.z, nz ? hiz.w : loz.w};
+                const float farz[4] = {nz ? loz.x : hiz.x, nz ? loz.y : hiz.y, nz ? loz.z : hiz.z, nz ? loz.w : hiz.w};
+                uint32_t hit_mask = 0;
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    float tmin = 0.0f, tmax = ray_end_t, t_dom;
+                    float t0 = inv.x * (nearx[c] - o.x);
+                    float t1 = sinv.x * (farx[c] - o.x);
+                    t_dom = t0;
+                    tmin = fmaxf(tmin, t0);
+                    tmax = fminf(tmax, t1);
+                    t0 = inv.y * (neary[c] - o.y);
+                    t1 = sinv.y * (fary[c] - o.y);
+                    t_dom = shear.kz == 1 ? t0 : t_dom;
+                    tmin = fmaxf(tmin, t0);
+                    tmax = fminf(tmax, t1);
+                    t0 = inv.z * (nearz[c] - o.z);
+                    t1 = sinv.z * (farz[c] - o.z);
+                    t_dom = shear.kz == 2 ? t0 : t_dom;
+                    tmin = fmaxf(tmin, t0);
+                    tmax = fminf(tmax, t1);
+                    if ((uint32_t)c < n_children && (0.0f <= tmin) && (tmin <= tmax) && (t_dom <= best.th.t * kCullSlack)) hit_mask |= 1u << c;
+                }
+                if (COUNT) (*n_nodes_visited) += n_children;
+#pragma unroll
+                for (int k = 3; k >= 0; k--) {  // last to visit first, so that the first is on top
+                    const uint32_t c = (perm >> (2 * k)) & 3u;
+                    if ((uint32_t)k < n_children && ((hit_mask >> c) & 1u) && sp < sc.wide_stack) {
+                        stack[sp * kBlock] = c == 0u ? refs[0] : (c == 1u ? refs[1] : (c == 2u ? refs[2] : refs[3]));
+                        sp++;
+                    }
+                }
+            }
+            if (sp > 0) cur = stack[(--sp) * kBlock];
+            else have = false;
+        }
+        if (n_pend == 0) break;
+        for (uint32_t j = 0; j < n_pend; j++) {
+            const uint32_t ref = pend[j * kBlock];
+            if (bvh_test_leaf<COUNT, ANY_HIT>(sc, o, shear, ray_end_t, ref & 0xffffffu, ((ref >> 24) & 0x7fu) + 1u, best, n_tris_tested)) return best;
+        }
+    }
+    if (!(best.th.t != ray_end_t)) best.prim = kNoHit;  // bvh.rs:137
+    if (!ANY_HIT && best.prim != kNoHit) best.tag = f2u(sc.tri_v[3 * best.prim + 2].w);
+    return best;
+}
+template <bool COUNT, bool ANY_HIT = false, bool WIDE = false>
 PT_D Hit bvh_intersect(const SceneDev& sc, V3 o, V3 d, float ray_end_t, uint32_t* n_nodes_visited, uint32_t* n_tris_tested) {
+    if (WIDE) return bvh_intersect_wide<COUNT, ANY_HIT>(sc, o, d, ray_end_t, n_nodes_visited, n_tris_tested);
     extern __shared__ uint32_t sm_bvh_stack[];
     uint32_t* stack = sm_bvh_stack + threadIdx.x;
     Hit best;
@@ -473,9 +595,9 @@ PT_D Hit bvh_intersect(const SceneDev& sc, V3 o, V3 d, float ray_end_t, uint32_t
     return best;
 }
 // Scene::occluded (scene.rs:229-235): unnormalised segment, t_max 0.9999; only the boolean leaves this function.
-template <bool COUNT = false>
+template <bool COUNT = false, bool WIDE = false>
 PT_D bool scene_occluded(const SceneDev& sc, V3 from, V3 to, uint32_t* n_nodes = nullptr, uint32_t* n_tris = nullptr) {
-    Hit h = bvh_intersect<COUNT, true>(sc, from, to - from, 0.9999f, n_nodes, n_tris);
+    Hit h = bvh_intersect<COUNT, true, WIDE>(sc, from, to - from, 0.9999f, n_nodes, n_tris);
     return h.prim != kNoHit;
 }
 

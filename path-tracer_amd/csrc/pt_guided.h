@@ -823,16 +823,16 @@ __global__ __launch_bounds__(kBlock, KINDS != 7 ? PT_GUIDED_DIFFUSE_WAVES : PT_S
 }
 
 // NEE visibility for the guided walk: shade wrote the sample into the vertex as if visible; a blocked one is cleared.
-template <bool CENSUS>
+template <bool CENSUS, bool WIDE>
 __global__ __launch_bounds__(kBlock) void k_occlude_guided(SceneDev sc, GuidedParams gp, ShadowCols sh, const RoundCounters* cnt, unsigned long long* census) {
     const uint32_t n = cnt->n_shadow;
     if (blockIdx.x * blockDim.x >= n) return;  // late rounds: most workgroups have nothing to do, not even staging nodes
-    bvh_stage_nodes(sc);
+    bvh_stage_nodes<WIDE>(sc);
     const uint32_t stride = gridDim.x * blockDim.x;
     uint32_t cn = 0, ct = 0;
     for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) {
         const float4 a = sh.q0[j], b = sh.q1[j];
-        if (scene_occluded<CENSUS>(sc, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), &cn, &ct)) {
+        if (scene_occluded<CENSUS, WIDE>(sc, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), &cn, &ct)) {
             float4* v = gp.vtx.at(f2u(b.w), f2u(a.w));
             v[VTX_LI0] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             v[VTX_LI1] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);

@@ -11,6 +11,9 @@ namespace pt {
 #ifndef PT_SHADE_WAVES
 #define PT_SHADE_WAVES 2  // minimum waves per SIMD the shade kernels are compiled for (register budget 512 / N)
 #endif
+#ifndef PT_WIDE_WAVES
+#define PT_WIDE_WAVES 6  // waves per SIMD the four-wide walkers are compiled for (a wide node is 32 registers of loads in flight: at 8 they spill)
+#endif
 #ifndef PT_PATH_DIFFUSE_WAVES
 #define PT_PATH_DIFFUSE_WAVES 3  // k_shade_path without conductors: 3 waves per SIMD fit (171 registers otherwise, one too many)
 #endif
@@ -273,21 +276,21 @@ __global__ __launch_bounds__(kBlock) void k_raygen_camera(SceneDev sc, CameraDev
 
 // ------------------------------------------------------------------ extend (closest hit)
 // Scene::intersect -> Bvh::intersect (scene.rs:184-186, bvh.rs:86-142) for slots [0, n_active).
-template <bool CENSUS>
 // `top` (may be null) counts the entries queued from the top of the state set (slot_of_index).
-__global__ __launch_bounds__(kBlock, 8) void k_extend(SceneDev sc, PathCols st, HitCols hit, const RoundCounters* cnt, unsigned long long* census, const uint32_t* top,
+template <bool CENSUS, bool WIDE>
+__global__ __launch_bounds__(kBlock, WIDE ? PT_WIDE_WAVES : 8) void k_extend(SceneDev sc, PathCols st, HitCols hit, const RoundCounters* cnt, unsigned long long* census, const uint32_t* top,
                                                       uint32_t capacity) {
     const uint32_t n_bottom = cnt->n_active;
     const uint32_t n = n_bottom + (top ? *top : 0u);
     if (blockIdx.x * blockDim.x >= n) return;  // late rounds: most workgroups have nothing to do, not even staging nodes
-    bvh_stage_nodes(sc);
+    bvh_stage_nodes<WIDE>(sc);
     const uint32_t stride = gridDim.x * blockDim.x;
     uint32_t cn = 0, ct = 0;
     for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) {
         const uint32_t i = slot_of_index(j, n_bottom, capacity);
         float4 o = st.o_pdf[i], d = st.d_flags[i];
         asm volatile("" : "+v"(o.x), "+v"(o.y), "+v"(o.z), "+v"(d.x), "+v"(d.y), "+v"(d.z));  // one load each (see bvh_intersect)
-        const Hit h = bvh_intersect<CENSUS>(sc, mk3(o.x, o.y, o.z), mk3(d.x, d.y, d.z), f_inf(), &cn, &ct);
+        const Hit h = bvh_intersect<CENSUS, false, WIDE>(sc, mk3(o.x, o.y, o.z), mk3(d.x, d.y, d.z), f_inf(), &cn, &ct);
         hit.tb[i] = make_float4(h.th.t, h.th.b0, h.th.b1, h.th.b2);
         hit.prim[i] = make_uint2(h.prim, h.tag);
     }
@@ -299,15 +302,15 @@ struct HitOut {
     uint32_t mesh_index, triangle_index, leaf_index, hit;
     float t, b0, b1, b2;
 };
-template <bool COUNT>  // COUNT: the instrumented walk (nodes popped, triangles tested), as the census variants of the stages
+template <bool COUNT, bool WIDE>  // COUNT: the instrumented walk (nodes popped, triangles tested), as the census variants of the stages
 __global__ __launch_bounds__(kBlock) void k_trace_batch(SceneDev sc, const float* rays, uint32_t n, HitOut* out, unsigned long long* counts) {
-    bvh_stage_nodes(sc);
+    bvh_stage_nodes<WIDE>(sc);
     const uint32_t stride = gridDim.x * blockDim.x;
     unsigned long long nn = 0, nt = 0;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const float* r = rays + 7 * (size_t)i;
         uint32_t a = 0, b = 0;
-        const Hit h = bvh_intersect<COUNT>(sc, mk3(r[0], r[1], r[2]), mk3(r[3], r[4], r[5]), r[6], &a, &b);
+        const Hit h = bvh_intersect<COUNT, false, WIDE>(sc, mk3(r[0], r[1], r[2]), mk3(r[3], r[4], r[5]), r[6], &a, &b);
         nn += a;
         nt += b;
         HitOut o;
@@ -328,13 +331,14 @@ __global__ __launch_bounds__(kBlock) void k_trace_batch(SceneDev sc, const float
         atomicAdd(counts + 1, nt);
     }
 }
+template <bool WIDE>
 __global__ __launch_bounds__(kBlock) void k_occluded_batch(SceneDev sc, const float* from, const float* to, uint32_t n, uint8_t* out) {
-    bvh_stage_nodes(sc);
+    bvh_stage_nodes<WIDE>(sc);
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const float* a = from + 3 * (size_t)i;
         const float* b = to + 3 * (size_t)i;
-        out[i] = scene_occluded(sc, mk3(a[0], a[1], a[2]), mk3(b[0], b[1], b[2])) ? 1 : 0;
+        out[i] = scene_occluded<false, WIDE>(sc, mk3(a[0], a[1], a[2]), mk3(b[0], b[1], b[2])) ? 1 : 0;
     }
 }
 
@@ -492,11 +496,11 @@ __global__ __launch_bounds__(kBlock, KINDS != 7 ? PT_PATH_DIFFUSE_WAVES : PT_SHA
 // ------------------------------------------------------------------ occlude: `path` integrator
 // Scene::occluded for the NEE shadow rays of this round; adds the MIS-weighted contribution to the path's
 // radiance and finishes paths that ended in shade with this ray still pending.
-template <bool CENSUS>
-__global__ __launch_bounds__(kBlock, 8) void k_occlude_path(SceneDev sc, RenderParams rp, PathCols st, ShadowCols sh, const RoundCounters* cnt, unsigned long long* census) {
+template <bool CENSUS, bool WIDE>
+__global__ __launch_bounds__(kBlock, WIDE ? PT_WIDE_WAVES : 8) void k_occlude_path(SceneDev sc, RenderParams rp, PathCols st, ShadowCols sh, const RoundCounters* cnt, unsigned long long* census) {
     const uint32_t n = cnt->n_shadow;
     if (blockIdx.x * blockDim.x >= n) return;  // late rounds: most workgroups have nothing to do, not even staging nodes
-    bvh_stage_nodes(sc);
+    bvh_stage_nodes<WIDE>(sc);
     const uint32_t stride = gridDim.x * blockDim.x;
     uint32_t cn = 0, ct = 0;
     for (uint32_t base = blockIdx.x * blockDim.x; base < n; base += stride) {  // block-uniform trip count
@@ -506,7 +510,7 @@ __global__ __launch_bounds__(kBlock, 8) void k_occlude_path(SceneDev sc, RenderP
         double rgb[3] = {0.0, 0.0, 0.0};
         if (j < n) {
             const float4 a = sh.q0[j], b = sh.q1[j];
-            const bool occ = scene_occluded<CENSUS>(sc, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), &cn, &ct);
+            const bool occ = scene_occluded<CENSUS, WIDE>(sc, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), &cn, &ct);
             const uint32_t target = f2u(a.w);
             const uint32_t slot = target & ~kTerminalBit;
             if (target & kTerminalBit) {
@@ -688,11 +692,11 @@ __global__ __launch_bounds__(kBlock, PT_SHADE_WAVES) void k_shade_light(SceneDev
 }
 
 // Camera-connection visibility + Film::add_splat (camera.rs:161-166) with f64 atomics.
-template <bool CENSUS>
+template <bool CENSUS, bool WIDE>
 __global__ __launch_bounds__(kBlock) void k_occlude_splat(SceneDev sc, RenderParams rp, ShadowCols sh, const RoundCounters* cnt, unsigned long long* census) {
     const uint32_t n = cnt->n_shadow;
     if (blockIdx.x * blockDim.x >= n) return;  // late rounds: most workgroups have nothing to do, not even staging nodes
-    bvh_stage_nodes(sc);
+    bvh_stage_nodes<WIDE>(sc);
     const uint32_t stride = gridDim.x * blockDim.x;
     const double* r = reinterpret_cast<const double*>(sh.q2);
     uint32_t cn = 0, ct = 0;
@@ -703,7 +707,7 @@ __global__ __launch_bounds__(kBlock) void k_occlude_splat(SceneDev sc, RenderPar
         double rgb[3] = {0.0, 0.0, 0.0};
         if (j < n) {
             const float4 a = sh.q0[j], b = sh.q1[j];
-            if (!scene_occluded<CENSUS>(sc, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), &cn, &ct)) {
+            if (!scene_occluded<CENSUS, WIDE>(sc, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), &cn, &ct)) {
                 rgb[0] = r[3 * (size_t)j];
                 rgb[1] = r[3 * (size_t)j + 1];
                 rgb[2] = r[3 * (size_t)j + 2];

@@ -62,6 +62,11 @@ struct SceneDev {
     uint32_t n_nodes, n_tris, n_emissive_tris, n_emissive_meshes;
     uint32_t lds_nodes;                // != 0: the kernels copy the node array (n_nodes * 32 B, small scenes) into LDS behind the stacks (bvh_stage_nodes)
     uint32_t bvh_stack;                // LDS stack entries per ray = tree depth + 1 (kernels get 256 * bvh_stack * 4 B of dynamic LDS)
+    // four-wide image of the same tree (bvh_build.h: WideNode; eight float4 per node), walked by the WIDE kernel variants
+    const float4* wnodes;
+    uint32_t n_wnodes;
+    uint32_t wide_stack;               // LDS stack entries per ray of the wide walk = 3 * wide depth + 1
+    uint32_t lds_wnodes;               // != 0: the wide node array is staged in LDS
     V3 bounds_lo, bounds_hi;
     uint32_t* guards;                  // kGuard* counters: how often a documented safety limit cut something short (ptgpu_guard_counts)
 };

@@ -154,7 +154,11 @@ struct ptgpu_ctx {
     bool census_on = false;
     int kinds = 7;       // material kinds in use, rounded up to a compiled set (PT_LAUNCH_BY_KINDS)
     std::map<const void*, int> resident_blocks;  // per shade kernel: workgroups resident per CU (resident_grid)
-    size_t bvh_lds = 0;  // dynamic LDS bytes of every kernel that walks the BVH (pt_device.h: bvh_intersect)
+    size_t bvh_lds = 0;  // dynamic LDS bytes of every kernel that walks the BVH (pt_device.h: bvh_intersect), for the mode in use
+    size_t bvh_lds_mode[2] = {0, 0};  // binary walk, wide walk
+    bool wide = false;     // walk the four-wide image of the BVH (same hits; ptgpu_set_traversal)
+    bool have_wide = false;
+    DevBuf<float4> d_wnodes;
     DevBuf<unsigned long long> d_census;  // extend nodes, extend tris, occlude nodes, occlude tris
     DevBuf<uint32_t> d_guards;            // kGuard* counters (pt_types.h), cumulative since ptgpu_init
     double stage_ms[PTGPU_N_STAGES] = {0, 0, 0, 0, 0, 0};
@@ -194,10 +198,17 @@ int resident_grid(ptgpu_ctx* c, const void* kernel, int grid, size_t dynamic_lds
 // Kernels that walk the BVH keep their traversal stacks (and small node arrays) in dynamic LDS sized from the scene's
 // tree depth (c->bvh_lds, 15 KB for the Cornell box, 35 KB at depth 25, 74 KB at the reference's limit of 64 levels): the
 // grid is what is resident with THAT much LDS per workgroup (the cache is per scene: ptgpu_scene_create clears it).
+// Every kernel that walks the BVH exists for the binary and for the four-wide image of the tree (ptgpu_set_traversal).
+#define PT_WALKER(c, kernel, census) ((c)->wide ? kernel<census, true> : kernel<census, false>)
 #define PT_LAUNCH_WALK(c, kernel, grid, ...) \
     hipLaunchKernelGGL(kernel, dim3(resident_grid((c), (const void*)kernel, (grid), (c)->bvh_lds)), dim3(kBlock), (c)->bvh_lds, (c)->stream, __VA_ARGS__)
 // Above 64 KB per workgroup a kernel must be told so before its first launch (up to the CU's 160 KB).
 constexpr size_t kLdsDefaultLimit = 64 * 1024, kLdsPerCu = 160 * 1024;
+// Default traversal of a new scene unless PTGPU_BVH_WIDE says otherwise: the four-wide walk for trees whose binary nodes
+// exceed this many bytes. Measured (profiles/r02_traversal_modes.txt): where the nodes sit in LDS or L1 the binary walk's
+// cheaper steps win (Cornell box: extend 8.1 ms against 9.1), where every step is a round trip to L2 the wide walk's
+// fewer steps do (veach-mis, 61 492 triangles: extend 25.2 -> 22.2 ms, occlusion 22.9 -> 20.0); veach-bidir (0.7 MB) is even.
+constexpr size_t kWideAboveBytes = 1u << 20;
 
 int grid_for(const ptgpu_ctx* c, uint64_t n) {
     const uint64_t want = (n + kBlock - 1) / kBlock;
@@ -488,15 +499,43 @@ int ptgpu_scene_create(ptgpu_ctx* c, const ptgpu_scene_desc* desc) {
     s.n_emissive_meshes = n_emissive_meshes;
     s.bvh_stack = bvh_depth + 1;
     s.lds_nodes = (n_nodes * 32 <= kLdsNodeBudget) ? 1u : 0u;
-    c->bvh_lds = (size_t)kBlock * (s.bvh_stack + 2 * kLeafQueue) * sizeof(uint32_t) + (s.lds_nodes ? n_nodes * 32 : 0);
+    c->bvh_lds_mode[0] = (size_t)kBlock * (s.bvh_stack + 2 * kLeafQueue) * sizeof(uint32_t) + (s.lds_nodes ? n_nodes * 32 : 0);
+    {
+        // the four-wide image of the same tree (bvh_build.h)
+        std::vector<WideNode> wide;
+        uint32_t wide_depth = 0;
+        c->have_wide = build_wide(bvh, wide, wide_depth);
+        if (!c->have_wide) wide.assign(1, WideNode{});
+        std::vector<float4> wn(8 * wide.size());
+        memcpy(wn.data(), wide.data(), wide.size() * sizeof(WideNode));
+        HIP_TRY(c->d_wnodes.upload(wn, c->stream));
+        s.wnodes = c->d_wnodes.p;
+        s.n_wnodes = (uint32_t)wide.size();
+        s.wide_stack = 3 * wide_depth + 1;
+        s.lds_wnodes = (wide.size() * sizeof(WideNode) <= kLdsNodeBudget) ? 1u : 0u;
+        c->bvh_lds_mode[1] = (size_t)kBlock * (s.wide_stack + kLeafQueue) * sizeof(uint32_t) + (s.lds_wnodes ? wide.size() * sizeof(WideNode) : 0);
+        if (c->bvh_lds_mode[1] > kLdsPerCu) c->have_wide = false;
+    }
+    static const char* env_wide = getenv("PTGPU_BVH_WIDE");  // default traversal of new scenes: 1 = four-wide, 0 = binary
+    c->wide = c->have_wide && (env_wide ? atoi(env_wide) != 0 : n_nodes * 32 > kWideAboveBytes);
+    c->bvh_lds = c->bvh_lds_mode[c->wide ? 1 : 0];
     c->resident_blocks.clear();
-    if (c->bvh_lds > kLdsPerCu) return fail(PTGPU_E_LIMIT, "scene_create: traversal stacks exceed the CU's LDS");
-    if (c->bvh_lds > kLdsDefaultLimit) {
-        const void* walkers[] = {(const void*)k_trace_batch<true>,    (const void*)k_trace_batch<false>,   (const void*)k_occluded_batch,
-                                 (const void*)k_extend<true>,         (const void*)k_extend<false>,        (const void*)k_occlude_path<true>,
-                                 (const void*)k_occlude_path<false>,  (const void*)k_occlude_splat<true>,  (const void*)k_occlude_splat<false>,
-                                 (const void*)k_occlude_guided<true>, (const void*)k_occlude_guided<false>};
-        for (const void* k : walkers) HIP_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->bvh_lds));
+    if (c->bvh_lds_mode[0] > kLdsPerCu) return fail(PTGPU_E_LIMIT, "scene_create: traversal stacks exceed the CU's LDS");
+    if (std::max(c->bvh_lds_mode[0], c->have_wide ? c->bvh_lds_mode[1] : 0) > kLdsDefaultLimit) {
+        const int lds_b = (int)c->bvh_lds_mode[0], lds_w = (int)std::max(c->bvh_lds_mode[1], (size_t)1);
+#define PT_SET_LDS(kernel)                                                                                             \
+    HIP_TRY(hipFuncSetAttribute((const void*)kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b)); \
+    HIP_TRY(hipFuncSetAttribute((const void*)kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b)); \
+    HIP_TRY(hipFuncSetAttribute((const void*)kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_w));  \
+    HIP_TRY(hipFuncSetAttribute((const void*)kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_w));
+        PT_SET_LDS(k_trace_batch)
+        PT_SET_LDS(k_extend)
+        PT_SET_LDS(k_occlude_path)
+        PT_SET_LDS(k_occlude_splat)
+        PT_SET_LDS(k_occlude_guided)
+#undef PT_SET_LDS
+        HIP_TRY(hipFuncSetAttribute((const void*)k_occluded_batch<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_occluded_batch<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_w));
     }
     s.bounds_lo = bvh.nodes[0].bounds.lo;
     s.bounds_hi = bvh.nodes[0].bounds.hi;
@@ -583,9 +622,9 @@ int ptgpu_trace_batch(ptgpu_ctx* c, const float* rays, uint32_t n, ptgpu_hit* hi
     {
         StageTimer st(c, PTGPU_STAGE_EXTEND);
         if (c->census_on)
-            PT_LAUNCH_WALK(c, HIP_KERNEL_NAME(k_trace_batch<true>), grid_for(c, n), c->scene, d_rays.p, n, d_hits.p, c->d_census.p);
+            PT_LAUNCH_WALK(c, PT_WALKER(c, k_trace_batch, true), grid_for(c, n), c->scene, d_rays.p, n, d_hits.p, c->d_census.p);
         else
-            PT_LAUNCH_WALK(c, HIP_KERNEL_NAME(k_trace_batch<false>), grid_for(c, n), c->scene, d_rays.p, n, d_hits.p, (unsigned long long*)nullptr);
+            PT_LAUNCH_WALK(c, PT_WALKER(c, k_trace_batch, false), grid_for(c, n), c->scene, d_rays.p, n, d_hits.p, (unsigned long long*)nullptr);
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(hits_out, d_hits.p, (size_t)n * sizeof(HitOut), hipMemcpyDeviceToHost, c->stream));
@@ -607,7 +646,7 @@ int ptgpu_trace_batch_noalloc(ptgpu_ctx* c, const float* rays, uint32_t n, ptgpu
     HitOut* d_hits = reinterpret_cast<HitOut*>(c->scratch + kNoAllocRayBytes);
     // nothing in the scratch has to start at zero: the kernel writes every hit record in [0, n) and reads only rays [0, n)
     HIP_TRY(hipMemcpyAsync(d_rays, rays, 7 * (size_t)n * sizeof(float), hipMemcpyHostToDevice, c->stream));
-    PT_LAUNCH_WALK(c, HIP_KERNEL_NAME(k_trace_batch<false>), grid_for(c, n), c->scene, d_rays, n, d_hits, (unsigned long long*)nullptr);
+    PT_LAUNCH_WALK(c, PT_WALKER(c, k_trace_batch, false), grid_for(c, n), c->scene, d_rays, n, d_hits, (unsigned long long*)nullptr);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(hits_out, d_hits, (size_t)n * sizeof(HitOut), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -626,7 +665,7 @@ int ptgpu_occluded_batch(ptgpu_ctx* c, const float* from, const float* to, uint3
     HIP_TRY(d_out.alloc(n));
     HIP_TRY(hipMemcpyAsync(d_from.p, from, 3 * (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(d_to.p, to, 3 * (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
-    PT_LAUNCH_WALK(c, k_occluded_batch, grid_for(c, n), c->scene, d_from.p, d_to.p, n, d_out.p);
+    PT_LAUNCH_WALK(c, ((c)->wide ? k_occluded_batch<true> : k_occluded_batch<false>), grid_for(c, n), c->scene, d_from.p, d_to.p, n, d_out.p);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(out, d_out.p, n, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -638,6 +677,15 @@ int ptgpu_set_profiling(ptgpu_ctx* c, int enabled) {
     c->profiling = enabled != 0;
     return PTGPU_OK;
 }
+int ptgpu_set_traversal(ptgpu_ctx* c, int wide) {
+    if (!c || !c->have_scene) return fail(PTGPU_E_STATE, "set_traversal: no scene");
+    if (wide && !c->have_wide) return fail(PTGPU_E_LIMIT, "set_traversal: this scene has no four-wide tree (a leaf with more than 128 triangles, or more than 2^24 triangles)");
+    c->wide = wide != 0;
+    c->bvh_lds = c->bvh_lds_mode[c->wide ? 1 : 0];
+    c->resident_blocks.clear();
+    return PTGPU_OK;
+}
+int ptgpu_get_traversal(ptgpu_ctx* c) { return (c && c->wide) ? 1 : 0; }
 int ptgpu_kernel_times(ptgpu_ctx* c, double* ms_out, uint64_t* launches_out, uint32_t n) {
     if (!c) return fail(PTGPU_E_INVALID, "kernel_times: NULL ctx");
     for (uint32_t i = 0; i < n && i < PTGPU_N_STAGES; i++) {
@@ -688,8 +736,8 @@ int ptgpu_set_batch_paths(ptgpu_ctx* c, uint32_t n_paths) {
 namespace {
 
 void launch_extend(ptgpu_ctx* c, int grid, const PathCols& A, const HitCols& H, const RoundCounters* cnt, const uint32_t* top = nullptr) {
-    if (c->census_on) PT_LAUNCH_WALK(c, HIP_KERNEL_NAME(k_extend<true>), grid, c->scene, A, H, cnt, c->d_census.p, top, c->capacity);
-    else PT_LAUNCH_WALK(c, HIP_KERNEL_NAME(k_extend<false>), grid, c->scene, A, H, cnt, c->d_census.p, top, c->capacity);
+    if (c->census_on) PT_LAUNCH_WALK(c, PT_WALKER(c, k_extend, true), grid, c->scene, A, H, cnt, c->d_census.p, top, c->capacity);
+    else PT_LAUNCH_WALK(c, PT_WALKER(c, k_extend, false), grid, c->scene, A, H, cnt, c->d_census.p, top, c->capacity);
 }
 
 int upload_lambda_table(ptgpu_ctx* c, const std::vector<float>& u) {
@@ -738,8 +786,8 @@ int run_batch_path_like(ptgpu_ctx* c, bool light, const RenderParams& rp, uint32
             hipLaunchKernelGGL(k_raygen_light, dim3(grid), dim3(kBlock), 0, c->stream, c->scene, c->camera, rp, A, S, cnt, n_paths, npix, first_sample, sample_step);
         }
         StageTimer t(c, PTGPU_STAGE_OCCLUDE);
-        if (c->census_on) PT_LAUNCH_WALK(c, HIP_KERNEL_NAME(k_occlude_splat<true>), grid, c->scene, rp, S, cnt, c->d_census.p);
-        else PT_LAUNCH_WALK(c, HIP_KERNEL_NAME(k_occlude_splat<false>), grid, c->scene, rp, S, cnt, c->d_census.p);
+        if (c->census_on) PT_LAUNCH_WALK(c, PT_WALKER(c, k_occlude_splat, true), grid, c->scene, rp, S, cnt, c->d_census.p);
+        else PT_LAUNCH_WALK(c, PT_WALKER(c, k_occlude_splat, false), grid, c->scene, rp, S, cnt, c->d_census.p);
     } else {
         StageTimer t(c, PTGPU_STAGE_RAYGEN);
         hipLaunchKernelGGL(k_raygen_camera, dim3(grid), dim3(kBlock), 0, c->stream, c->scene, c->camera, rp, A, cnt, n_paths, npix, first_sample, sample_step);
@@ -764,11 +812,11 @@ int run_batch_path_like(ptgpu_ctx* c, bool light, const RenderParams& rp, uint32
         {
             StageTimer t(c, PTGPU_STAGE_OCCLUDE);
             if (light) {
-                if (c->census_on) PT_LAUNCH_WALK(c, HIP_KERNEL_NAME(k_occlude_splat<true>), grid, c->scene, rp, S, cnt + round + 1, c->d_census.p);
-                else PT_LAUNCH_WALK(c, HIP_KERNEL_NAME(k_occlude_splat<false>), grid, c->scene, rp, S, cnt + round + 1, c->d_census.p);
+                if (c->census_on) PT_LAUNCH_WALK(c, PT_WALKER(c, k_occlude_splat, true), grid, c->scene, rp, S, cnt + round + 1, c->d_census.p);
+                else PT_LAUNCH_WALK(c, PT_WALKER(c, k_occlude_splat, false), grid, c->scene, rp, S, cnt + round + 1, c->d_census.p);
             } else {
-                if (c->census_on) PT_LAUNCH_WALK(c, HIP_KERNEL_NAME(k_occlude_path<true>), grid, c->scene, rp, B, S, cnt + round + 1, c->d_census.p);
-                else PT_LAUNCH_WALK(c, HIP_KERNEL_NAME(k_occlude_path<false>), grid, c->scene, rp, B, S, cnt + round + 1, c->d_census.p);
+                if (c->census_on) PT_LAUNCH_WALK(c, PT_WALKER(c, k_occlude_path, true), grid, c->scene, rp, B, S, cnt + round + 1, c->d_census.p);
+                else PT_LAUNCH_WALK(c, PT_WALKER(c, k_occlude_path, false), grid, c->scene, rp, B, S, cnt + round + 1, c->d_census.p);
             }
         }
         HIP_TRY(hipGetLastError());
