@@ -796,6 +796,10 @@ __global__ __launch_bounds__(kBlock, KINDS != 7 ? PT_GUIDED_DIFFUSE_WAVES : PT_S
         PT_TICK(8);
         uint32_t a_slot, s_slot;
         const bool to_top = alive && (flags & FLAG_INSIDE) != 0;  // the next surface is, in all likelihood, the body's own: specular
+#ifdef PT_DBG_TIMING
+        lds_barrier();
+        PT_TICK(19);  // waiting for the block's other waves to arrive
+#endif
         block_alloc3(sm_alloc, nxt, nxt_top, rp.capacity, alive && !to_top, to_top, want_shadow, a_slot, s_slot);
         PT_TICK(9);
         n_shaded += shaded ? 1u : 0u;
