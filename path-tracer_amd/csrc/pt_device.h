@@ -247,6 +247,20 @@ PT_HD V3 offset_ray_origin(V3 blo, V3 bhi, V3 n, V3 w) {
     return po;
 }
 
+// offset_ray_origin with its direction-independent part computed ahead: `mag` = offset_magnitude(blo, bhi, n), `p` =
+// the box's centre (the interaction point). Same operations, same bits; a caller that must keep the surface over long
+// code keeps one float instead of the box.
+PT_HD float offset_magnitude(V3 blo, V3 bhi, V3 n) { return fabsf(dot(n, max3(bhi - blo, splat(kEps)))); }
+PT_HD V3 offset_ray_origin_from(V3 p, V3 n, float mag, V3 w) {
+    V3 off = mag * n;
+    if (dot(w, n) < 0.0f) off = -off;
+    V3 po = p + off;
+    po.x = off.x > 0.0f ? next_up(po.x) : next_down(po.x);
+    po.y = off.y > 0.0f ? next_up(po.y) : next_down(po.y);
+    po.z = off.z > 0.0f ? next_up(po.z) : next_down(po.z);
+    return po;
+}
+
 PT_HD V3 permute_kz(V3 v, int kz) { return kz == 0 ? mk3(v.y, v.z, v.x) : (kz == 1 ? mk3(v.z, v.x, v.y) : v); }
 PT_HD float diff_of_products(float a, float b, float c, float d) {  // geom.rs:195-200
     float cd = c * d;

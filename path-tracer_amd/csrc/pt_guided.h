@@ -216,6 +216,12 @@ PT_HD int cell_child_of(Cell c, V2 p, Cell& out) {  // child_index (dtree.rs:331
 }
 constexpr uint32_t kMaxQuadLevel = 24;
 constexpr uint32_t kWeightCopies = 16;
+// The per-level pdf factors of a descent wait in LDS (dtree_pdf below). Each wave owns a [kMaxQuadLevel + 1][64] block
+// of the workgroup's array — lane-interleaved, conflict-free — so that a wave may reuse its block for something else
+// once its descent is over without caring where the workgroup's other waves are.
+constexpr uint32_t kScaleStride = 64;
+constexpr uint32_t kScaleWaveFloats = (kMaxQuadLevel + 1) * kScaleStride;
+PT_D float* scales_of(float* sm, uint32_t tid) { return sm + (tid / 64u) * kScaleWaveFloats + (tid % 64u); }
 
 // DTree::sample (dtree.rs:98-153): one float per level, two at the leaf.
 PT_D V2 dtree_sample(const SdTreeDev& t, uint4 leaf, Rng& rng) {
@@ -243,7 +249,7 @@ PT_D V2 dtree_sample(const SdTreeDev& t, uint4 leaf, Rng& rng) {
     }
 }
 // DTree::pdf (dtree.rs:155-179): prod over levels of 4 * child / sum, times 1 / 4 pi.
-// `scales` is this lane's column of a [kMaxQuadLevel + 1][kBlock] LDS array: the per-level factors are multiplied
+// `scales` is this lane's column of its wave's [kMaxQuadLevel + 1][64] LDS block (scales_of): the per-level factors are multiplied
 // innermost first, as the reference's recursion does, so they have to be kept until the leaf is reached.
 PT_D float dtree_pdf(const SdTreeDev& t, uint4 leaf, V2 p, float* scales) {
     if (leaf.z) return kInvFourPi;
@@ -267,11 +273,11 @@ PT_D float dtree_pdf(const SdTreeDev& t, uint4 leaf, V2 p, float* scales) {
             result = scale;
             break;
         }
-        scales[(n++) * kBlock] = scale;
+        scales[(n++) * kScaleStride] = scale;
         ni = link;
         cell = child;
     }
-    for (int i = n - 1; i >= 0; i--) result = scales[i * kBlock] * result;  // innermost first, as the recursion multiplies
+    for (int i = n - 1; i >= 0; i--) result = scales[i * kScaleStride] * result;  // innermost first, as the recursion multiplies
     return result * kInvFourPi;
 }
 
@@ -321,7 +327,7 @@ PT_D float dtree_walk(const SdTreeDev& t, uint4 leaf, bool sample, Rng& rng, V2&
             result = scale;
             break;
         }
-        scales[(n++) * kBlock] = scale;
+        scales[(n++) * kScaleStride] = scale;
         ni = link;
         r = t.s_node[leaf.x + ni].rad;
         links = t.s_node[leaf.x + ni].child;
@@ -334,7 +340,7 @@ PT_D float dtree_walk(const SdTreeDev& t, uint4 leaf, bool sample, Rng& rng, V2&
         sq = clamp2(s, V2{0.0f, 0.0f}, V2{1.0f, 1.0f});
         if (redo || !(sq.x >= cb.lo.x && sq.x < cb.hi.x && sq.y >= cb.lo.y && sq.y < cb.hi.y)) return dtree_pdf(t, leaf, sq, scales);
     }
-    for (int i = n - 1; i >= 0; i--) result = scales[i * kBlock] * result;  // innermost first, as the recursion multiplies
+    for (int i = n - 1; i >= 0; i--) result = scales[i * kScaleStride] * result;  // innermost first, as the recursion multiplies
     return result * kInvFourPi;
 }
 
@@ -592,30 +598,51 @@ __global__ __launch_bounds__(kBlock) void k_raygen_guided(SceneDev sc, CameraDev
     }
 }
 
-// A stored vertex is written in two steps to keep registers free over the long sampling code in between: what is known
-// when the surface has been shaded (emitted light, the direct-light sample) goes into the vertex's row at once —
-// harmless if the vertex is not stored after all, the row stays beyond the path's count — the sampled direction
-// later. The direct-light sample is written as if visible; k_occlude_guided clears it when the shadow ray is blocked.
+// A stored vertex leaves the kernel as ONE 128-byte line written by eight neighbouring lanes. Compaction scatters paths
+// over lanes, so a lane that writes its own line in 16-byte pieces touches a line of its own with every store
+// instruction (64 partly written lines per instruction, six instructions per vertex): measured, those stores were 50 ms
+// of the 166 ms the kernel takes per step. Instead every lane parks its line in LDS — the emitted light and the
+// direct-light sample as soon as they are known (they would otherwise hold 16 registers over the long sampling code),
+// position, direction and throughput at the end, in the space the wave's pdf factors have vacated by then — and the wave
+// then writes the parked lines out, eight lanes per line: full lines, one request each, nothing for the memory side
+// to merge. The direct-light sample is written as if visible; k_occlude_guided clears it when the shadow ray is blocked.
 // The emitted light of a vertex is zero unless the path has just hit an emitter, its direct light is zero when no light
-// sample was made: each one's 32 bytes are written, and later added by the record pass, only when present (`has_emitted`,
-// `has_li`: bits 0 and 1 of the line's spare word, which store_vertex writes).
-PT_D void store_vertex_light(const GuidedParams& gp, uint32_t row, uint32_t pid, const Spec& e, const Spec& li, bool has_emitted, bool has_li) {
-    float4* v = gp.vtx.at(row, pid);
+// sample was made: the record pass adds each only when present (`has_emitted`, `has_li`: bits 0 and 1 of the line's
+// spare word); an absent field of the line holds whatever the LDS held.
+// Piece k (VTX_*) of lane l sits at [k][(l + k) % 64] of the wave's block: lanes write consecutive 16-byte cells, and
+// the eight lanes that later read pieces 0..7 of one line fall into eight different bank groups.
+constexpr uint32_t kNoLine = 0xffffffffu;
+PT_D float4* stage_cell(float4* lo, float4* hi, uint32_t piece, uint32_t lane) { return (piece < 4u ? lo : hi - 4u * 64u) + piece * 64u + ((lane + piece) & 63u); }
+PT_D void stage_vertex_light(float4* hi, uint32_t lane, const Spec& e, const Spec& li, bool has_emitted, bool has_li) {
     if (has_emitted) {
-        v[VTX_E0] = make_float4(e.v[0], e.v[1], e.v[2], e.v[3]);
-        v[VTX_E1] = make_float4(e.v[4], e.v[5], e.v[6], e.v[7]);
+        *stage_cell(nullptr, hi, VTX_E0, lane) = make_float4(e.v[0], e.v[1], e.v[2], e.v[3]);
+        *stage_cell(nullptr, hi, VTX_E1, lane) = make_float4(e.v[4], e.v[5], e.v[6], e.v[7]);
     }
     if (has_li) {
-        v[VTX_LI0] = make_float4(li.v[0], li.v[1], li.v[2], li.v[3]);
-        v[VTX_LI1] = make_float4(li.v[4], li.v[5], li.v[6], li.v[7]);
+        *stage_cell(nullptr, hi, VTX_LI0, lane) = make_float4(li.v[0], li.v[1], li.v[2], li.v[3]);
+        *stage_cell(nullptr, hi, VTX_LI1, lane) = make_float4(li.v[4], li.v[5], li.v[6], li.v[7]);
     }
 }
-PT_D void store_vertex(const GuidedParams& gp, uint32_t row, uint32_t pid, V3 p, V3 wi, float pdf, const Spec& f, bool has_emitted, bool has_li) {
-    float4* v = gp.vtx.at(row, pid);
-    v[VTX_P_PDF] = make_float4(p.x, p.y, p.z, pdf);
-    v[VTX_WI] = make_float4(wi.x, wi.y, wi.z, u2f((has_emitted ? 1u : 0u) | (has_li ? 2u : 0u)));
-    v[VTX_F0] = make_float4(f.v[0], f.v[1], f.v[2], f.v[3]);
-    v[VTX_F1] = make_float4(f.v[4], f.v[5], f.v[6], f.v[7]);
+PT_D void stage_vertex(float4* lo, uint32_t lane, V3 p, V3 wi, float pdf, const Spec& f, bool has_emitted, bool has_li) {
+    *stage_cell(lo, nullptr, VTX_P_PDF, lane) = make_float4(p.x, p.y, p.z, pdf);
+    *stage_cell(lo, nullptr, VTX_WI, lane) = make_float4(wi.x, wi.y, wi.z, u2f((has_emitted ? 1u : 0u) | (has_li ? 2u : 0u)));
+    *stage_cell(lo, nullptr, VTX_F0, lane) = make_float4(f.v[0], f.v[1], f.v[2], f.v[3]);
+    *stage_cell(lo, nullptr, VTX_F1, lane) = make_float4(f.v[4], f.v[5], f.v[6], f.v[7]);
+}
+// Called by the whole wave: `line` = index of this lane's parked line in the vertex store, or kNoLine.
+PT_D void stage_write_out(float4* lines, float4* lo, float4* hi, uint32_t line) {
+    asm volatile("" ::: "memory");  // the parking stores above stay above
+    const unsigned long long have = __ballot(line != kNoLine);
+    if (have == 0ull) return;
+    const uint32_t lane = __lane_id(), piece = lane & 7u;
+#pragma unroll
+    for (uint32_t s = 0; s < 8; s++) {
+        if (((have >> (8u * s)) & 0xffull) == 0ull) continue;  // wave-uniform
+        const uint32_t src = 8u * s + (lane >> 3);
+        const uint32_t at = (uint32_t)__shfl((int)line, (int)src);
+        if (at != kNoLine) lines[(size_t)at * 8u + piece] = *stage_cell(lo, hi, piece, src);
+    }
+    asm volatile("" ::: "memory");  // ... and the block's next use below
 }
 
 // One iteration of PathGuidingIntegrator::random_walk's loop body (mod.rs:139-278).
@@ -624,7 +651,14 @@ __global__ __launch_bounds__(kBlock, KINDS != 7 ? PT_GUIDED_DIFFUSE_WAVES : PT_S
                                                          ShadowCols sh, const RoundCounters* cur, RoundCounters* nxt, const uint32_t* cur_top, uint32_t* nxt_top) {
     __shared__ BlockAlloc3 sm_alloc;
     __shared__ uint32_t sm_count;
-    __shared__ float sm_scales[(kMaxQuadLevel + 1) * kBlock];
+    __shared__ __align__(16) float sm_scales[(kBlock / 64u) * kScaleWaveFloats];
+    __shared__ float4 sm_stage_hi[(kBlock / 64u) * 4u * 64u];
+    __shared__ float sm_shadow[6 * kBlock];
+    static_assert(kScaleWaveFloats >= 4u * 64u * 4u && (kScaleWaveFloats * sizeof(float)) % 16u == 0, "pieces 0-3 of a wave's lines are parked in its block of pdf factors");
+    // (recomputed where used rather than kept: the kernel sits at its register cap)
+#define PT_MY_SCALES scales_of(sm_scales, threadIdx.x)
+#define PT_STAGE_LO reinterpret_cast<float4*>(sm_scales + (threadIdx.x / 64u) * kScaleWaveFloats)
+#define PT_STAGE_HI (sm_stage_hi + (threadIdx.x / 64u) * 4u * 64u)
     PT_TICK_INIT();
     uint32_t n_shaded = 0, n_skipped = 0;
     const uint32_t n_bottom = cur->n_active;
@@ -636,8 +670,9 @@ __global__ __launch_bounds__(kBlock, KINDS != 7 ? PT_GUIDED_DIFFUSE_WAVES : PT_S
         const bool valid = j < n;
         const uint32_t i = slot_of_index(j, n_bottom, rp.capacity);
         bool alive = false, want_shadow = false, shaded = false, skipped_shadow = false, ended = false;
-        V3 o = mk3(0, 0, 0), d = mk3(0, 0, 1), sh_from = mk3(0, 0, 0), sh_to = mk3(0, 0, 0);
-        uint32_t flags = 0, pid = 0, nverts = 0, shadow_row = 0;
+        V3 o = mk3(0, 0, 0), d = mk3(0, 0, 1);
+        uint32_t flags = 0, pid = 0, nverts = 0;
+        bool stored = false, miss_vertex = false;  // stored: this lane fills vertex row nverts - 1 of its path in this trip
         Spec beta = spec_splat(0.0f);
         uint4 rp4 = make_uint4(0, 0, 0, 0);
         if (valid) {
@@ -654,8 +689,7 @@ __global__ __launch_bounds__(kBlock, KINDS != 7 ? PT_GUIDED_DIFFUSE_WAVES : PT_S
             if (prim == kNoHit) {
                 // miss vertex (mod.rs:140-150): far point along the ray, nothing emitted without an envmap
                 if (nverts < gp.n_rows) {
-                    store_vertex_light(gp, nverts, pid, spec_splat(0.0f), spec_splat(0.0f), false, false);
-                    store_vertex(gp, nverts, pid, o + d * 10000.0f, d, 1.0f, spec_splat(1.0f), false, false);
+                    miss_vertex = stored = true;  // parked below, once every lane of the wave is done with its pdf factors
                     nverts++;
                 } else
                     atomicAdd(sc.guards + kGuardVertexStore, 1u);
@@ -742,17 +776,24 @@ __global__ __launch_bounds__(kBlock, KINDS != 7 ? PT_GUIDED_DIFFUSE_WAVES : PT_S
                                     contrib = w * f * le;
                                 }
                                 const V3 w = normalize(lp - p);
-                                sh_from = offset_ray_origin(sf.blo, sf.bhi, sf.ng, w);
-                                sh_to = lp;
+                                // the shadow ray waits in LDS for its queue slot, not in six registers over the sampling code
+                                const V3 sh_from = offset_ray_origin(sf.blo, sf.bhi, sf.ng, w);
+                                sm_shadow[0 * kBlock + threadIdx.x] = sh_from.x;
+                                sm_shadow[1 * kBlock + threadIdx.x] = sh_from.y;
+                                sm_shadow[2 * kBlock + threadIdx.x] = sh_from.z;
+                                sm_shadow[3 * kBlock + threadIdx.x] = lp.x;
+                                sm_shadow[4 * kBlock + threadIdx.x] = lp.y;
+                                sm_shadow[5 * kBlock + threadIdx.x] = lp.z;
                                 has_nee = true;
                             }
                         }
                     }
+                    const float off_mag = offset_magnitude(sf.blo, sf.bhi, sf.ng);  // what the next ray's origin needs of the error box
                     const bool has_emitted = !spec_is_black(emitted);
-                    if (!specular && nverts < gp.n_rows) store_vertex_light(gp, nverts, pid, emitted, contrib, has_emitted, has_nee);
+                    if (!specular && nverts < gp.n_rows) stage_vertex_light(PT_STAGE_HI, __lane_id(), emitted, contrib, has_emitted, has_nee);
                     PT_TICK(2);
                     BsdfSample bs;
-                    const bool ok = guider_sample(tree, bsdf, sf.frame, sf.ng, wo, rng, sm_scales + threadIdx.x, sampler_word, root, bs PT_DBG_ARGS);
+                    const bool ok = guider_sample(tree, bsdf, sf.frame, sf.ng, wo, rng, PT_MY_SCALES, sampler_word, root, bs PT_DBG_ARGS);
                     rp4.x = (uint32_t)rng.state;
                     rp4.y = (uint32_t)(rng.state >> 32);
                     if (!ok) {
@@ -768,8 +809,9 @@ __global__ __launch_bounds__(kBlock, KINDS != 7 ? PT_GUIDED_DIFFUSE_WAVES : PT_S
 #pragma unroll
                         for (int k = 0; k < NSW; k++) fw.v[k] = bs.f.v[k] / bs.pdf;
                         if (!specular && nverts < gp.n_rows) {
-                            store_vertex(gp, nverts, pid, p, bs.wi, bs.pdf, fw, has_emitted, has_nee);
-                            shadow_row = nverts;
+                            // every lane of the wave that descends a quadtree in this trip has done so: the factors' space is free
+                            stage_vertex(PT_STAGE_LO, __lane_id(), p, bs.wi, bs.pdf, fw, has_emitted, has_nee);
+                            stored = true;
                             want_shadow = has_nee;
                             nverts++;
                         } else {
@@ -780,7 +822,7 @@ __global__ __launch_bounds__(kBlock, KINDS != 7 ? PT_GUIDED_DIFFUSE_WAVES : PT_S
                         if (spec_is_black(beta)) ended = true;
                         else {
                             if (bs.terminate_secondary) flags |= FLAG_SECONDARY_TERMINATED;
-                            o = offset_ray_origin(sf.blo, sf.bhi, sf.ng, bs.wi);
+                            o = offset_ray_origin_from(p, sf.ng, off_mag, bs.wi);
                             d = bs.wi;
                             depth += 1;
                             flags = (flags & ~FLAG_DEPTH_MASK) | (depth & FLAG_DEPTH_MASK);
@@ -793,6 +835,8 @@ __global__ __launch_bounds__(kBlock, KINDS != 7 ? PT_GUIDED_DIFFUSE_WAVES : PT_S
             }
             rp4.w = (rp4.w & 0xffffu) | (nverts << 16);
         }
+        if (miss_vertex) stage_vertex(PT_STAGE_LO, __lane_id(), o + d * 10000.0f, d, 1.0f, spec_splat(1.0f), false, false);
+        stage_write_out(gp.vtx.lines, PT_STAGE_LO, PT_STAGE_HI, stored ? pid * gp.n_rows + (nverts - 1u) : kNoLine);
         PT_TICK(8);
         uint32_t a_slot, s_slot;
         const bool to_top = alive && (flags & FLAG_INSIDE) != 0;  // the next surface is, in all likelihood, the body's own: specular
@@ -800,7 +844,11 @@ __global__ __launch_bounds__(kBlock, KINDS != 7 ? PT_GUIDED_DIFFUSE_WAVES : PT_S
         lds_barrier();
         PT_TICK(19);  // waiting for the block's other waves to arrive
 #endif
+#ifdef PT_WAVE_ALLOC
+        wave_alloc3(nxt, nxt_top, rp.capacity, alive && !to_top, to_top, want_shadow, a_slot, s_slot);
+#else
         block_alloc3(sm_alloc, nxt, nxt_top, rp.capacity, alive && !to_top, to_top, want_shadow, a_slot, s_slot);
+#endif
         PT_TICK(9);
         n_shaded += shaded ? 1u : 0u;
         n_skipped += skipped_shadow ? 1u : 0u;
@@ -815,8 +863,8 @@ __global__ __launch_bounds__(kBlock, KINDS != 7 ? PT_GUIDED_DIFFUSE_WAVES : PT_S
             gp.tail.nverts_flags[pid] = flags;
         }
         if (want_shadow) {
-            sh.q0[s_slot] = make_float4(sh_from.x, sh_from.y, sh_from.z, u2f(pid));
-            sh.q1[s_slot] = make_float4(sh_to.x, sh_to.y, sh_to.z, u2f(shadow_row));
+            sh.q0[s_slot] = make_float4(sm_shadow[0 * kBlock + threadIdx.x], sm_shadow[1 * kBlock + threadIdx.x], sm_shadow[2 * kBlock + threadIdx.x], u2f(pid));
+            sh.q1[s_slot] = make_float4(sm_shadow[3 * kBlock + threadIdx.x], sm_shadow[4 * kBlock + threadIdx.x], sm_shadow[5 * kBlock + threadIdx.x], u2f(nverts - 1u));  // the row just stored
         }
         PT_TICK(10);
     }
@@ -974,7 +1022,7 @@ __global__ __launch_bounds__(kBlock) void k_guided_selfcheck(SdTreeDev tree, uin
         if (plain != leaf_id || !same_box || (word & 0x7fffffffu) != li.x || (word >> 31) != li.z) atomicAdd(counts + 4, 1ull);
     }
     const uint4 leaf = make_uint4(word & 0x7fffffffu, 0u, word >> 31, 0u);
-    float* scales = sm_scales + threadIdx.x;
+    float* scales = scales_of(sm_scales, threadIdx.x);
     // (a) separate descents
     Rng ra = rng;
     const V2 sq_a = dtree_sample(tree, leaf, ra);
@@ -1010,7 +1058,7 @@ __global__ __launch_bounds__(kBlock) void k_guided_probe(SdTreeDev tree, const f
     const uint32_t leaf_id = stree_leaf<true>(tree, p, lo, hi, &word);
     const uint32_t word2 = stree_resolve(tree, tree.top[stree_code(tree, p)], p);
     const uint4 leaf = make_uint4(word & 0x7fffffffu, 0u, word >> 31, 0u);
-    float* scales = sm_scales + threadIdx.x;
+    float* scales = scales_of(sm_scales, threadIdx.x);
     Rng rng = rng_init_pixel(i & 0xffffu, i >> 16, seed);
     V2 sq = V2{0.0f, 0.0f};
     const SNode root = tree.s_node[leaf.x];
