@@ -844,11 +844,7 @@ __global__ __launch_bounds__(kBlock, KINDS != 7 ? PT_GUIDED_DIFFUSE_WAVES : PT_S
         lds_barrier();
         PT_TICK(19);  // waiting for the block's other waves to arrive
 #endif
-#ifdef PT_WAVE_ALLOC
-        wave_alloc3(nxt, nxt_top, rp.capacity, alive && !to_top, to_top, want_shadow, a_slot, s_slot);
-#else
         block_alloc3(sm_alloc, nxt, nxt_top, rp.capacity, alive && !to_top, to_top, want_shadow, a_slot, s_slot);
-#endif
         PT_TICK(9);
         n_shaded += shaded ? 1u : 0u;
         n_skipped += skipped_shadow ? 1u : 0u;

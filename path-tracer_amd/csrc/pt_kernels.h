@@ -103,25 +103,6 @@ PT_D void block_alloc3(BlockAlloc3& sm, RoundCounters* rc, uint32_t* top, uint32
     slot_a = want_t ? capacity - 1u - (sm.base[1] + wt + (uint32_t)__popcll(mt & below)) : sm.base[0] + wa + (uint32_t)__popcll(ma & below);
     slot_b = sm.base[2] + wb + (uint32_t)__popcll(mb & below);
 }
-// The same three classes allocated per WAVE: no LDS, no workgroup barrier — the four waves of a workgroup drift apart
-// over a long loop body (different tree depths, different memory latencies) and a barrier per trip makes every wave wait
-// for the slowest. One returning 64-bit atomic per wave and trip (plus one on `top` when the wave has such lanes).
-PT_D void wave_alloc3(RoundCounters* rc, uint32_t* top, uint32_t capacity, bool want_a, bool want_t, bool want_b, uint32_t& slot_a, uint32_t& slot_b) {
-    const uint32_t lane = __lane_id();
-    const unsigned long long ma = __ballot(want_a), mt = __ballot(want_t), mb = __ballot(want_b);
-    unsigned long long old = 0;
-    uint32_t old_t = 0;
-    if (lane == 0) {
-        const unsigned long long add = (unsigned long long)__popcll(ma) | ((unsigned long long)__popcll(mb) << 32);
-        if (add) old = atomicAdd(reinterpret_cast<unsigned long long*>(&rc->n_active), add);
-        if (mt) old_t = atomicAdd(top, (uint32_t)__popcll(mt));
-    }
-    const uint32_t base_a = (uint32_t)__shfl((int)(uint32_t)old, 0), base_b = (uint32_t)__shfl((int)(uint32_t)(old >> 32), 0);
-    old_t = (uint32_t)__shfl((int)old_t, 0);
-    const unsigned long long below = (1ull << lane) - 1ull;
-    slot_a = want_t ? capacity - 1u - (old_t + (uint32_t)__popcll(mt & below)) : base_a + (uint32_t)__popcll(ma & below);
-    slot_b = base_b + (uint32_t)__popcll(mb & below);
-}
 // Sum of a per-thread count over the block, added to *counter once (call after the loop, by every thread).
 PT_D void block_count_flush(uint32_t* sm_word, uint32_t* counter, uint32_t mine) {
     if (threadIdx.x == 0) *sm_word = 0;
