@@ -38,6 +38,9 @@ PT_D void dbg_tick(unsigned long long* w, int k) {
 #define PT_TICK_FLUSH() do {} while (0)
 #endif
 
+#ifndef PT_SCAN_WAVES
+#define PT_SCAN_WAVES 3  // k_guide_scan holds two rows of lines (64 registers): 4 waves per SIMD spill 152 bytes and run slower (30.6 against 28.2 ms per step)
+#endif
 #ifndef PT_GUIDED_DIFFUSE_WAVES
 #define PT_GUIDED_DIFFUSE_WAVES 3
 #endif
@@ -836,7 +839,7 @@ __global__ __launch_bounds__(kBlock, KINDS != 7 ? PT_GUIDED_DIFFUSE_WAVES : PT_S
             rp4.w = (rp4.w & 0xffffu) | (nverts << 16);
         }
         if (miss_vertex) stage_vertex(PT_STAGE_LO, __lane_id(), o + d * 10000.0f, d, 1.0f, spec_splat(1.0f), false, false);
-        stage_write_out(gp.vtx.lines, PT_STAGE_LO, PT_STAGE_HI, stored ? pid * gp.n_rows + (nverts - 1u) : kNoLine);
+        stage_write_out(gp.vtx.lines, PT_STAGE_LO, PT_STAGE_HI, stored ? (nverts - 1u) * gp.vtx.n_paths + pid : kNoLine);
         PT_TICK(8);
         uint32_t a_slot, s_slot;
         const bool to_top = alive && (flags & FLAG_INSIDE) != 0;  // the next surface is, in all likelihood, the body's own: specular
@@ -905,8 +908,9 @@ struct RecordQueue {
     uint32_t* count;  // records per chunk
 };
 
-__global__ __launch_bounds__(kBlock) void k_guide_scan(SceneDev sc, RenderParams rp, GuidedParams gp, RecordQueue rq, uint32_t n_paths) {
+__global__ __launch_bounds__(kBlock, PT_SCAN_WAVES) void k_guide_scan(SceneDev sc, RenderParams rp, GuidedParams gp, RecordQueue rq, uint32_t n_paths) {
     __shared__ uint32_t sm_n;
+    __shared__ float4 sm_stage[(kBlock / 64u) * 8u * 64u];  // per wave: the 64 lines of one row, on their way from the lanes that fetched them to their paths
     const uint32_t n_chunks = (n_paths + kBlock - 1) / kBlock;
     const uint32_t lane = __lane_id();
     for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
@@ -927,22 +931,34 @@ __global__ __launch_bounds__(kBlock) void k_guide_scan(SceneDev sc, RenderParams
         Spec l = spec_splat(0.0f);
         const size_t base = (size_t)chunk * kBlock * gp.n_rows;
         // The lines of a path are read back to front, and nothing in a line's address depends on the line before it: the
-        // next line is requested whole before this one is folded in (two lines in flight per lane). Whole, because a
+        // next row is requested whole before this one is folded in (two rows in flight per wave). Whole, because a
         // half asked for one trip later has left L2 by then and comes from HBM a second time (measured: +24 % traffic).
+        // A row is fetched as it was written (stage_write_out): eight neighbouring lanes read the eight pieces of one
+        // line — a lane that reads its own line in 16-byte pieces keeps the address pipeline busy four cycles per piece
+        // (64 lines per instruction), which bounded this kernel at 2.2 TB/s (TA busy 0.9) — and the lines change hands in LDS.
+        const uint32_t pid0 = chunk * kBlock + (threadIdx.x & ~63u);  // the wave's first path: lane s holds path pid0 + s
+        float4* const stage = sm_stage + (threadIdx.x / 64u) * 8u * 64u;
         float4 nx[8];
-        for (int k = 0; k < 8; k++) nx[k] = make_float4(0, 0, 0, 0);
-        if (wave_rows > 0 && wave_rows - 1 < nverts) {
-            const float4* vx = gp.vtx.at(wave_rows - 1, pid);
-            for (int k = 0; k < 8; k++) nx[k] = vx[k];
-        }
+        const auto fetch_row = [&](uint32_t row) {
+            const unsigned long long has = __ballot(row < nverts);
+#pragma unroll
+            for (uint32_t k = 0; k < 8; k++) {
+                const uint32_t src = 8u * k + (lane >> 3);
+                nx[k] = make_float4(0, 0, 0, 0);
+                if ((has >> src) & 1ull) nx[k] = gp.vtx.at(row, pid0)[64u * k + lane];  // = piece lane % 8 of path pid0 + src: consecutive lanes, consecutive addresses
+            }
+        };
+        if (wave_rows > 0) fetch_row(wave_rows - 1);
         for (uint32_t v = wave_rows; v-- > 0;) {
             bool want = false;
             float4 cur[8];
-            for (int k = 0; k < 8; k++) cur[k] = nx[k];
-            if (v > 0 && v - 1 < nverts) {
-                const float4* vn = gp.vtx.at(v - 1, pid);
-                for (int k = 0; k < 8; k++) nx[k] = vn[k];
-            }
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (uint32_t k = 0; k < 8; k++) *stage_cell(stage, stage + 4u * 64u, lane & 7u, 8u * k + (lane >> 3)) = nx[k];
+            asm volatile("" ::: "memory");
+            if (v > 0) fetch_row(v - 1);
+#pragma unroll
+            for (uint32_t k = 0; k < 8; k++) cur[k] = *stage_cell(stage, stage + 4u * 64u, k, lane);  // (read where used: the compiler sinks them)
             const float4 pp = cur[VTX_P_PDF], wi = cur[VTX_WI];
             float radiance = 0.0f, u0 = 0.0f, u1 = 0.0f, u2 = 0.0f;
             if (v < nverts) {

@@ -74,14 +74,17 @@ constexpr int kMaxRounds = 1 << 16;
 PT_HD uint32_t slot_of_index(uint32_t j, uint32_t n_bottom, uint32_t capacity) { return j < n_bottom ? j : capacity - 1u - (j - n_bottom); }
 
 // Guided integrator: per-path vertex store (PathVertex, path_guiding/mod.rs:281-289). One vertex = one 128-byte
-// line of eight float4 {p.xyz|wi_pdf, wi.xyz|-, f/pdf (2), emitted (2), li_sample_contribution (2)}, the rows of a
-// path back to back: vertex (row, path) sits at line path * n_rows + row. Survivors are compacted every round, so
-// the lanes of a wave hold unrelated paths at different depths: whole-line records keep each lane's store (shade)
-// and load (record scan) one full line instead of eight scattered 16-byte pieces.
+// line of eight float4 {p.xyz|wi_pdf, wi.xyz|-, f/pdf (2), emitted (2), li_sample_contribution (2)}; vertex (row, path)
+// sits at line row * n_paths + path. Survivors are compacted every round, so the lanes of a wave hold unrelated paths
+// at different depths and the shade kernel's stores are scattered lines whatever the order; the record scan, which has
+// one lane per path and walks the rows back to front, finds row v of 64 neighbouring paths in 8 KB of consecutive
+// memory (with a path's rows back to back instead it read 128-byte pieces 2 KB apart: 2.2 TB/s, the rate of random
+// DRAM accesses).
 struct VertexStore {
     float4* lines;
     uint32_t n_rows;
-    PT_HD float4* at(uint32_t row, uint32_t path) const { return lines + ((size_t)path * n_rows + row) * 8; }
+    uint32_t n_paths;  // paths per batch (the context's capacity)
+    PT_HD float4* at(uint32_t row, uint32_t path) const { return lines + ((size_t)row * n_paths + path) * 8; }
 };
 enum { VTX_P_PDF = 0, VTX_WI = 1, VTX_F0 = 2, VTX_F1 = 3, VTX_E0 = 4, VTX_E1 = 5, VTX_LI0 = 6, VTX_LI1 = 7 };
 constexpr size_t kVertexBytes = 8 * 16;

@@ -7,7 +7,7 @@ for L in "$@"; do
   if [ "$L" = default ]; then P=$GRAFT_REPO_ROOT/path-tracer_amd/lib/libptgpu.so; else P=$GRAFT_REPO_ROOT/path-tracer_amd/lib/variants/$L; fi
   OUT=/tmp/kt_$L; rm -rf $OUT; mkdir -p $OUT
   export PTGPU_LIB=$P PTGPU_NO_OVERLAP=1
-  timeout -s KILL 240 rocprofv3 --kernel-trace --output-format csv -d $OUT -o kt -- python3 tools/render_once.py 512 1 > $OUT/run.log 2>&1 || { tail -5 $OUT/run.log; exit 1; }
+  timeout -s KILL 240 rocprofv3 --kernel-trace --output-format csv -d $OUT -o kt -- python3 tools/render_once.py 512 2 > $OUT/run.log 2>&1 || { tail -5 $OUT/run.log; exit 1; }
   F=$(find $OUT -name "*kernel_trace.csv" | head -1)
   python3 - "$F" gpurun_out/kt_${TAG}_$L.csv <<'PY'
 import csv, sys
