@@ -262,6 +262,20 @@ def main() -> int:
                 if kernel.split("+")[0] in kname:
                     roofline["traffic"] = int(d["hbm_bytes_per_launch"])
                     roofline["traffic_source"] = f"profiles/{cands[-1].name}"
+    # The record pass of one batch runs beside the walk of the next (second stream): a kernel's launch duration in the timed
+    # region is therefore its time on a SHARED GPU. One more, untimed, step with the streams serialised gives the dominant
+    # kernel's duration with the GPU to itself (what a roofline fraction of the kernel means); reported beside, never instead.
+    if guided and world == 1:
+        ctx.set_record_overlap(False)
+        ctx.set_profiling(True)
+        step(spp)
+        s_ms, s_n = ctx.kernel_times()[dom]
+        ctx.set_profiling(False)
+        ctx.set_record_overlap(True)
+        if s_n and s_ms > 0:
+            s_gbs = survey_bytes / args.steps / s_n / (s_ms / s_n * 1e-3) * 1e-9
+            roofline["serialized"] = {"avg_launch_ms": round(s_ms / s_n, 4), "launches": int(s_n), "achieved": round(s_gbs, 2), "frac": round(s_gbs / HBM_PEAK_GBS, 5),
+                                      "note": "same step with the record pass on the walk's stream (ptgpu_set_record_overlap(0)): the kernel alone on the GPU"}
     if census:
         n_ext, n_sh = max(1, st["extend_rays"]), max(1, st["shadow_rays"])
         roofline["census"] = {"nodes_per_extend_ray": round(census["extend_nodes"] / n_ext, 2), "tris_per_extend_ray": round(census["extend_tris"] / n_ext, 2),

@@ -219,6 +219,10 @@ int ptgpu_set_profiling(ptgpu_ctx* ctx, int enabled);
 enum { PTGPU_STAGE_RAYGEN = 0, PTGPU_STAGE_EXTEND = 1, PTGPU_STAGE_SHADE = 2, PTGPU_STAGE_OCCLUDE = 3, PTGPU_STAGE_RECORD = 4,
        PTGPU_STAGE_OTHER = 5, PTGPU_N_STAGES = 6 };
 int ptgpu_kernel_times(ptgpu_ctx* ctx, double* ms_out, uint64_t* launches_out, uint32_t n);
+/* guided: by default the record pass of one batch (second HIP stream) runs beside the walk of the next; with 0 every
+ * kernel has the GPU to itself (same results; about 1 % slower; per-kernel times that are the kernel's own). Initial
+ * value: on, unless the environment variable PTGPU_NO_OVERLAP is set. No counterpart in the reference (measurement hook). */
+int ptgpu_set_record_overlap(ptgpu_ctx* ctx, int enabled);
 /* Traversal census for roofline accounting (bench only; selects instrumented kernel variants, off by default):
  * out[0..3] = BVH nodes visited / triangles tested by extend rays, then by occlusion rays, since it was enabled. */
 int ptgpu_set_census(ptgpu_ctx* ctx, int enabled);

@@ -90,7 +90,7 @@ PTGPU_SYMBOLS = [
     "ptgpu_set_batch_paths", "ptgpu_kernel_times", "ptgpu_set_census", "ptgpu_census", "ptgpu_guided_selfcheck",
     "ptgpu_trace_batch_noalloc", "ptgpu_guided_tree_info", "ptgpu_guided_tree_download", "ptgpu_guided_probe",
     "ptgpu_guided_record_batch", "ptgpu_guided_refine", "ptgpu_guard_counts", "ptgpu_film_device", "ptgpu_set_traversal",
-    "ptgpu_get_traversal",
+    "ptgpu_get_traversal", "ptgpu_set_record_overlap",
 ]
 PTHOST_SYMBOLS = [
     "pthost_last_error", "pthost_scene_load", "pthost_scene_free", "pthost_scene_desc", "pthost_camera_desc",
@@ -325,6 +325,11 @@ class Context:
 
     def set_profiling(self, on: bool):
         self._check(self.lib.ptgpu_set_profiling(self.handle, 1 if on else 0))
+
+    def set_record_overlap(self, on: bool):
+        """guided: record pass of one batch beside the walk of the next (default) or every kernel alone on the GPU."""
+        self.lib.ptgpu_set_record_overlap.argtypes = [C.c_void_p, C.c_int]
+        self._check(self.lib.ptgpu_set_record_overlap(self.handle, 1 if on else 0))
 
     def set_batch_paths(self, n: int):
         self._check(self.lib.ptgpu_set_batch_paths(self.handle, n))

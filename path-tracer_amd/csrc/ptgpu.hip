@@ -167,6 +167,7 @@ struct ptgpu_ctx {
     GuidedState* guided = nullptr;
     GuidedPersist* guided_persist = nullptr;
     bool direct_splat = false;         // PTGPU_DIRECT_SPLAT, sampled at the start of a wave
+    bool record_overlap = getenv("PTGPU_NO_OVERLAP") == nullptr;  // guided: record pass on the second stream (ptgpu_set_record_overlap)
     bool film_ready = false;           // d_film_packed holds the film of the last completed render
     unsigned char* scratch = nullptr;  // device address of `scratch` on this context's GPU (hipGetSymbolAddress)
 };
@@ -675,6 +676,12 @@ int ptgpu_occluded_batch(ptgpu_ctx* c, const float* from, const float* to, uint3
 int ptgpu_set_profiling(ptgpu_ctx* c, int enabled) {
     if (!c) return fail(PTGPU_E_INVALID, "set_profiling: NULL ctx");
     c->profiling = enabled != 0;
+    return PTGPU_OK;
+}
+int ptgpu_set_record_overlap(ptgpu_ctx* c, int enabled) {
+    if (!c) return fail(PTGPU_E_INVALID, "set_record_overlap: NULL ctx");
+    if (c->guided) return fail(PTGPU_E_STATE, "set_record_overlap: not between guided_begin and guided_end");
+    c->record_overlap = enabled != 0;
     return PTGPU_OK;
 }
 int ptgpu_set_traversal(ptgpu_ctx* c, int wide) {
