@@ -845,10 +845,10 @@ PT_D float bsdf_pdf(const Bsdf& m, const Frame& fr, V3 wo, V3 wi) { return bsdf_
 struct Tri {
     V3 p0, p1, p2;
     uint32_t mesh;
-    uint32_t tag;  // material + 1 (0 = pass-through) | has_normals << 31
+    uint32_t tag;  // material + 1 (0 = pass-through) | kind << 28 | has_normals << 31 (pt_types.h)
 };
-PT_HD int tri_material(const Tri& t) { return (int)(t.tag & 0x7fffffffu) - 1; }
-PT_HD bool tri_has_normals(const Tri& t) { return (t.tag & 0x80000000u) != 0; }
+PT_HD int tri_material(const Tri& t) { return tag_material(t.tag); }
+PT_HD bool tri_has_normals(const Tri& t) { return (t.tag & kTagNormalsBit) != 0; }
 PT_D Tri load_tri(const SceneDev& sc, uint32_t k) {
     const float4 a = sc.tri_v[3 * k], b = sc.tri_v[3 * k + 1], c = sc.tri_v[3 * k + 2];
     return Tri{mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), f2u(a.w), f2u(c.w)};

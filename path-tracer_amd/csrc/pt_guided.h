@@ -38,6 +38,9 @@ PT_D void dbg_tick(unsigned long long* w, int k) {
 #define PT_TICK_FLUSH() do {} while (0)
 #endif
 
+#ifndef PT_SORT_SHADE_GUIDED
+#define PT_SORT_SHADE_GUIDED 1
+#endif
 #ifndef PT_SCAN_WAVES
 #define PT_SCAN_WAVES 3  // k_guide_scan holds two rows of lines (64 registers): 4 waves per SIMD spill 152 bytes and run slower (30.6 against 28.2 ms per step)
 #endif
@@ -654,6 +657,8 @@ __global__ __launch_bounds__(kBlock, KINDS != 7 ? PT_GUIDED_DIFFUSE_WAVES : PT_S
                                                          ShadowCols sh, const RoundCounters* cur, RoundCounters* nxt, const uint32_t* cur_top, uint32_t* nxt_top) {
     __shared__ BlockAlloc3 sm_alloc;
     __shared__ uint32_t sm_count;
+    __shared__ BlockSort sm_sort;
+    constexpr bool kSort = PT_SORT_SHADE_GUIDED && KINDS == 7;  // measured: a gain where conductors mix with other surfaces (veach-mis shade -9 %, veach-bidir -7 %), none or a loss on the Cornell box
     __shared__ __align__(16) float sm_scales[(kBlock / 64u) * kScaleWaveFloats];
     __shared__ float4 sm_stage_hi[(kBlock / 64u) * 4u * 64u];
     __shared__ float sm_shadow[6 * kBlock];
@@ -669,7 +674,15 @@ __global__ __launch_bounds__(kBlock, KINDS != 7 ? PT_GUIDED_DIFFUSE_WAVES : PT_S
     const uint32_t stride = gridDim.x * blockDim.x;
     const uint32_t n_iter = (n + stride - 1) / stride;
     for (uint32_t it = 0; it < n_iter; it++) {
-        const uint32_t j = it * stride + blockIdx.x * blockDim.x + threadIdx.x;
+        uint32_t j = it * stride + blockIdx.x * blockDim.x + threadIdx.x;
+        if (kSort) {  // lanes regrouped by BSDF code (pt_kernels.h: block_sort_by_class)
+            uint32_t cls = 3;
+            if (j < n) {
+                const uint2 pt = hit.prim[slot_of_index(j, n_bottom, rp.capacity)];
+                if (pt.x != kNoHit && tag_material(pt.y) >= 0) cls = tag_kind(pt.y);
+            }
+            j = it * stride + blockIdx.x * blockDim.x + block_sort_by_class(sm_sort, cls);
+        }
         const bool valid = j < n;
         const uint32_t i = slot_of_index(j, n_bottom, rp.capacity);
         bool alive = false, want_shadow = false, shaded = false, skipped_shadow = false, ended = false;
@@ -703,7 +716,7 @@ __global__ __launch_bounds__(kBlock, KINDS != 7 ? PT_GUIDED_DIFFUSE_WAVES : PT_S
                 beta = load_spec(in.beta0, in.beta1, i);
                 const uint32_t row = rp4.w & 0xffffu;  // wavelength-table row of this path
                 const Surface sf = make_surface(sc, prim, tb.y, tb.z, tb.w);
-                const int material = (int)(prim_tag.y & 0x7fffffffu) - 1;
+                const int material = tag_material(prim_tag.y);
                 uint32_t depth = flags & FLAG_DEPTH_MASK;
                 if (material < 0) {
                     // pass-through: no bounce counted and, unlike `path`, specular_bounce is left alone (mod.rs:153-156)

@@ -14,6 +14,9 @@ namespace pt {
 #ifndef PT_WIDE_WAVES
 #define PT_WIDE_WAVES 6  // waves per SIMD the four-wide walkers are compiled for (a wide node is 32 registers of loads in flight: at 8 they spill)
 #endif
+#ifndef PT_SORT_SHADE
+#define PT_SORT_SHADE 1  // shade kernels with more than one BSDF regroup a workgroup's lanes by material kind (block_sort_by_class)
+#endif
 #ifndef PT_PATH_DIFFUSE_WAVES
 #define PT_PATH_DIFFUSE_WAVES 3  // k_shade_path without conductors: 3 waves per SIMD fit (171 registers otherwise, one too many)
 #endif
@@ -102,6 +105,40 @@ PT_D void block_alloc3(BlockAlloc3& sm, RoundCounters* rc, uint32_t* top, uint32
     const unsigned long long below = (1ull << lane) - 1ull;
     slot_a = want_t ? capacity - 1u - (sm.base[1] + wt + (uint32_t)__popcll(mt & below)) : sm.base[0] + wa + (uint32_t)__popcll(ma & below);
     slot_b = sm.base[2] + wb + (uint32_t)__popcll(mb & below);
+}
+// Lanes of one workgroup trip regrouped by the code they are about to run. After a bounce the 256 entries a workgroup
+// reads hold a mix of surfaces — Lambertian, rough conductor, dielectric, misses — and a wave runs every BSDF's code
+// that one of its lanes needs (veach-mis, k_shade_path<7>: 0.34 of the VALU lanes active). The hit record carries the
+// material's kind (pt_types.h: tag), so before anything else is loaded the workgroup sorts its 256 indices by class
+// through LDS (a counting sort: ballots per class, one LDS word per (wave, class)) and lane t takes the t-th index of
+// the sorted order: waves become (nearly) uniform in class. Results do not depend on it: an entry is shaded by another
+// lane, nothing else. `cls` in [0, kSortClasses); returns the offset (0..255) of the entry this thread takes.
+// Every thread of the workgroup calls it (two barriers).
+constexpr uint32_t kSortClasses = 4;
+struct BlockSort {
+    uint32_t count[4][kSortClasses];  // [wave][class]
+    uint32_t order[kBlock];
+};
+PT_D uint32_t block_sort_by_class(BlockSort& sm, uint32_t cls) {
+    const uint32_t lane = __lane_id(), wave = threadIdx.x / 64u;
+    unsigned long long m[kSortClasses];
+#pragma unroll
+    for (uint32_t k = 0; k < kSortClasses; k++) m[k] = __ballot(cls == k);
+    if (lane < kSortClasses) sm.count[wave][lane] = (uint32_t)__popcll(lane == 0 ? m[0] : (lane == 1 ? m[1] : (lane == 2 ? m[2] : m[3])));
+    lds_barrier();
+    uint32_t base = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < kSortClasses; k++) {
+#pragma unroll
+        for (uint32_t w = 0; w < 4; w++) {
+            const uint32_t c = sm.count[w][k];
+            if (k < cls || (k == cls && w < wave)) base += c;
+        }
+    }
+    const unsigned long long mine = cls == 0 ? m[0] : (cls == 1 ? m[1] : (cls == 2 ? m[2] : m[3]));
+    sm.order[base + (uint32_t)__popcll(mine & ((1ull << lane) - 1ull))] = threadIdx.x;
+    lds_barrier();
+    return sm.order[threadIdx.x];
 }
 // Sum of a per-thread count over the block, added to *counter once (call after the loop, by every thread).
 PT_D void block_count_flush(uint32_t* sm_word, uint32_t* counter, uint32_t mine) {
@@ -349,12 +386,23 @@ __global__ __launch_bounds__(kBlock, KINDS != 7 ? PT_PATH_DIFFUSE_WAVES : PT_SHA
                                                        const RoundCounters* cur, RoundCounters* nxt) {
     __shared__ BlockAlloc sm_alloc;
     __shared__ uint32_t sm_count;
+    __shared__ BlockSort sm_sort;
+    constexpr bool kSort = PT_SORT_SHADE && KINDS == 7;  // measured: a gain where conductors mix with other surfaces (veach-mis shade -9 %, veach-bidir -7 %), none or a loss on the Cornell box
     uint32_t n_shaded = 0;
     const uint32_t n = cur->n_active;
     const uint32_t stride = gridDim.x * blockDim.x;
     const uint32_t n_iter = (n + stride - 1) / stride;  // same trip count for every thread: allocation is block-uniform
     for (uint32_t it = 0; it < n_iter; it++) {
-        const uint32_t i = it * stride + blockIdx.x * blockDim.x + threadIdx.x;
+        uint32_t i = it * stride + blockIdx.x * blockDim.x + threadIdx.x;
+        if (kSort) {
+            // class of entry i: 0 Lambertian, 1 dielectric, 2 conductor, 3 nothing to shade (miss, pass-through, beyond the queue)
+            uint32_t cls = 3;
+            if (i < n) {
+                const uint2 pt = hit.prim[i];
+                if (pt.x != kNoHit && tag_material(pt.y) >= 0) cls = tag_kind(pt.y);
+            }
+            i = it * stride + blockIdx.x * blockDim.x + block_sort_by_class(sm_sort, cls);
+        }
         const bool valid = i < n;
         bool alive = false, want_shadow = false, do_film = false, shaded = false;
         V3 o = mk3(0, 0, 0), d = mk3(0, 0, 1), prev_p = mk3(0, 0, 0);
@@ -382,7 +430,7 @@ __global__ __launch_bounds__(kBlock, KINDS != 7 ? PT_PATH_DIFFUSE_WAVES : PT_SHA
                 pid = f2u(pp.w);
                 beta = load_spec(in.beta0, in.beta1, i);
                 const Surface sf = make_surface(sc, prim, tb.y, tb.z, tb.w);
-                const int material = (int)(prim_tag.y & 0x7fffffffu) - 1;
+                const int material = tag_material(prim_tag.y);
                 uint32_t depth = flags & FLAG_DEPTH_MASK;
                 if (material < 0) {
                     // no BSDF: continue straight on, do not count a bounce (path_tracer.rs:76-80)
@@ -630,7 +678,7 @@ __global__ __launch_bounds__(kBlock, PT_SHADE_WAVES) void k_shade_light(SceneDev
             const Lambdas wl = load_lambdas(rp.lambda_tab, rp4.w, true);
             const uint2 prim_tag = hit.prim[i];
             const Surface sf = make_surface(sc, prim_tag.x, tb.y, tb.z, tb.w);
-            const int material = (int)(prim_tag.y & 0x7fffffffu) - 1;
+            const int material = tag_material(prim_tag.y);
             uint32_t depth = (flags & FLAG_DEPTH_MASK) + 1;  // iterations consumed including this one
             if (material < 0) {
                 o = offset_ray_origin(sf.blo, sf.bhi, sf.ng, d);

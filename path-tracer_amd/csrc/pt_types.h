@@ -20,6 +20,12 @@ constexpr uint32_t kStreeTopLevels = PT_STREE_TOP_LEVELS;  // guided: levels of 
 constexpr int kBvhStack = 64;   // ArrayVec<usize, 64> (pt/src/bvh.rs:94)
 
 enum { MAT_LAMBERTIAN = 0, MAT_DIELECTRIC = 1, MAT_CONDUCTOR = 2 };
+// A triangle's tag (third w word of its record, copied into the hit record): material + 1 in the low 28 bits (0 = a
+// pass-through surface), the material's kind in bits 28-29 (so that a shade kernel can group its lanes by BSDF code
+// before it has loaded anything else), has_normals in bit 31.
+constexpr uint32_t kTagMaterialMask = 0x0fffffffu, kTagKindShift = 28, kTagNormalsBit = 0x80000000u;
+PT_HD int tag_material(uint32_t tag) { return (int)(tag & kTagMaterialMask) - 1; }
+PT_HD uint32_t tag_kind(uint32_t tag) { return (tag >> kTagKindShift) & 3u; }
 enum { MODE_PT = 0, MODE_NEE = 1, MODE_MIS = 2 };
 
 struct SpectrumDev {

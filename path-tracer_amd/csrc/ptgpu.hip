@@ -433,9 +433,11 @@ int ptgpu_scene_create(ptgpu_ctx* c, const ptgpu_scene_desc* desc) {
         const uint32_t m = tri_mesh[id], t = tri_index[id];
         const ptgpu_mesh& mesh = desc->meshes[order[m]];
         const uint32_t idx[3] = {mesh.triangles[3 * t], mesh.triangles[3 * t + 1], mesh.triangles[3 * t + 2]};
-        // third tag: material + 1 (0 = pass-through surface) | has_normals << 31, so that shading a hit needs no
+        // third tag: material + 1 (0 = pass-through surface) | kind << 28 | has_normals << 31, so that shading a hit needs no
         // dependent mesh_info load after the triangle fetch
-        const uint32_t tag[3] = {m, t, (uint32_t)(mesh_info[m].material + 1) | (mesh.normals ? 0x80000000u : 0u)};
+        const int mat = mesh_info[m].material;
+        const uint32_t kind = mat >= 0 ? (uint32_t)desc->materials[mat].kind & 3u : 0u;
+        const uint32_t tag[3] = {m, t, (uint32_t)(mat + 1) | (kind << kTagKindShift) | (mesh.normals ? kTagNormalsBit : 0u)};
         for (int v = 0; v < 3; v++) {
             const float* p = mesh.points + 3 * (size_t)idx[v];
             tri_v[3 * k + v] = make_float4(p[0], p[1], p[2], u2f(tag[v]));
