@@ -384,6 +384,33 @@ def test_guided_wave_api_and_stats_buffer(gpu_ctx):
         gpu_ctx.guided_wave(0)   # no begin
 
 
+def test_guided_record_pass_beside_or_behind_the_walk(gpu_ctx):
+    """ptgpu_set_record_overlap: with the record pass on the walk's own stream (every kernel alone on the GPU) the render
+    traces the same samples and grows the same tree as with the pass on the second stream, up to f32 atomic order."""
+    sc = pt.LoadedScene("cornell-box-guided", resx=64, resy=64, max_depth=8)
+    gpu_ctx.load(sc)
+    gpu_ctx.set_batch_paths(1 << 15)   # several batches per wave, so that there is something to overlap
+    out = {}
+    try:
+        for on in (True, False):
+            gpu_ctx.set_record_overlap(on)
+            out[on] = gpu_ctx.render(sc.integrator, 63)
+        gpu_ctx.guided_begin(sc.integrator, 3)
+        with pytest.raises(pt.PtError):
+            gpu_ctx.set_record_overlap(False)   # not in the middle of a guided render
+        for w in range(2):
+            gpu_ctx.guided_wave(w)
+        gpu_ctx.guided_end()
+    finally:
+        gpu_ctx.set_record_overlap(True)
+        gpu_ctx.set_batch_paths(0)
+    (fa, sa, sta), (fb, sb, stb) = out[True], out[False]
+    assert sa == sb and sta["samples"] == stb["samples"] == 64 * 64 * 63
+    assert sta["stree_nodes"] == stb["stree_nodes"]
+    assert abs(sta["dtree_nodes"] - stb["dtree_nodes"]) <= 0.01 * stb["dtree_nodes"] + 8
+    assert abs((fa * sa).mean() / (fb * sb).mean() - 1.0) < 0.01
+
+
 def test_guided_shards_cover_every_sample_once(gpu_ctx):
     sc = pt.LoadedScene("cornell-box-guided", resx=48, resy=40, max_depth=4)   # ragged tiles: 48x40 = 3x3 tiles, last row 8 high
     gpu_ctx.load(sc)
