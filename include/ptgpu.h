@@ -209,6 +209,12 @@ int ptgpu_occluded_batch(ptgpu_ctx* ctx, const float* from, const float* to, uin
  * nodes_out: n_nodes * 8 uint32 words = {min.xyz, max.xyz as f32 bits, offset, n_tris | split_axis << 16};
  * leaf_tris_out: n_tris * 2 uint32 = {mesh_index, triangle_index} in leaf order. Either may be NULL. */
 int ptgpu_scene_info(ptgpu_ctx* ctx, uint32_t* n_nodes, uint32_t* n_tris, uint32_t* n_emissive_tris, float bounds_out[6]);
+/* Where Bvh::new (bvh.rs:48-85,148-304) runs for the scenes created after the call: 0 = on the host, 1 = on the device,
+ * 2 = on the device for scenes of 16 384 triangles and more (the default). Both builders produce the same tree word for
+ * word (SAH decisions, itertools::partition order, depth-first numbering); the device builder hands inputs with a negative
+ * zero or a non-finite coordinate to the host one. ptgpu_bvh_built_on_device: 1 if the resident scene's tree was. */
+int ptgpu_set_bvh_builder(ptgpu_ctx* ctx, int mode);
+int ptgpu_bvh_built_on_device(ptgpu_ctx* ctx);
 int ptgpu_scene_bvh(ptgpu_ctx* ctx, uint32_t* nodes_out, uint32_t* leaf_tris_out);
 
 /* Timing hook for bench.py: when enabled, every kernel launch is bracketed by a pair of HIP events on the library's

@@ -90,7 +90,7 @@ PTGPU_SYMBOLS = [
     "ptgpu_set_batch_paths", "ptgpu_kernel_times", "ptgpu_set_census", "ptgpu_census", "ptgpu_guided_selfcheck",
     "ptgpu_trace_batch_noalloc", "ptgpu_guided_tree_info", "ptgpu_guided_tree_download", "ptgpu_guided_probe",
     "ptgpu_guided_record_batch", "ptgpu_guided_refine", "ptgpu_guard_counts", "ptgpu_film_device", "ptgpu_set_traversal",
-    "ptgpu_get_traversal", "ptgpu_set_record_overlap",
+    "ptgpu_get_traversal", "ptgpu_set_record_overlap", "ptgpu_set_bvh_builder", "ptgpu_bvh_built_on_device",
 ]
 PTHOST_SYMBOLS = [
     "pthost_last_error", "pthost_scene_load", "pthost_scene_free", "pthost_scene_desc", "pthost_camera_desc",
@@ -325,6 +325,15 @@ class Context:
 
     def set_profiling(self, on: bool):
         self._check(self.lib.ptgpu_set_profiling(self.handle, 1 if on else 0))
+
+    def set_bvh_builder(self, mode: int):
+        """Where the BVH of the scenes set after this call is built: 0 host, 1 device, 2 device from 16 384 triangles on (default)."""
+        self.lib.ptgpu_set_bvh_builder.argtypes = [C.c_void_p, C.c_int]
+        self._check(self.lib.ptgpu_set_bvh_builder(self.handle, mode))
+
+    def bvh_built_on_device(self) -> bool:
+        self.lib.ptgpu_bvh_built_on_device.argtypes = [C.c_void_p]
+        return bool(self.lib.ptgpu_bvh_built_on_device(self.handle))
 
     def set_record_overlap(self, on: bool):
         """guided: record pass of one batch beside the walk of the next (default) or every kernel alone on the GPU."""

@@ -2,6 +2,7 @@
 #include "../../include/ptgpu.h"
 
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -10,6 +11,7 @@
 #include <vector>
 
 #include "bvh_build.h"
+#include "pt_bvh_build.h"
 #include "cie_data.inc"
 #include "pt_guided.h"
 #include "pt_kernels.h"
@@ -166,6 +168,8 @@ struct ptgpu_ctx {
     uint64_t launches = 0;
     GuidedState* guided = nullptr;
     GuidedPersist* guided_persist = nullptr;
+    int bvh_builder = 2;               // ptgpu_set_bvh_builder: 0 host, 1 device, 2 device for scenes of kDeviceBuildFrom triangles and more
+    bool bvh_built_on_device = false;  // how the resident scene's tree was built
     bool direct_splat = false;         // PTGPU_DIRECT_SPLAT, sampled at the start of a wave
     bool record_overlap = getenv("PTGPU_NO_OVERLAP") == nullptr;  // guided: record pass on the second stream (ptgpu_set_record_overlap)
     bool film_ready = false;           // d_film_packed holds the film of the last completed render
@@ -354,6 +358,96 @@ void ptgpu_destroy(ptgpu_ctx* c) {
     delete c;
 }
 
+namespace {
+constexpr size_t kDeviceBuildFrom = 16384;  // below this the single-core host build takes a few milliseconds
+// Bvh::new on the device (pt_bvh_build.h). `built` = false: the input is one the device builder leaves to the host
+// (negative zeros, non-finite bounds, 2^24 triangles or more, an absurdly deep tree); `tris` is permuted as build_bvh does.
+int build_bvh_device(ptgpu_ctx* c, std::vector<BuildTri>& tris, FlatBvh& out, bool& built, bool& leaf_too_big) {
+    built = false;
+    leaf_too_big = false;
+    const size_t n = tris.size();
+    if (n == 0 || n >= (1u << 24)) return PTGPU_OK;
+    std::vector<float4> lo(n), hi(n);
+    for (size_t i = 0; i < n; i++) {
+        const Box3& b = tris[i].bounds;
+        const float v[6] = {b.lo.x, b.lo.y, b.lo.z, b.hi.x, b.hi.y, b.hi.z};
+        for (float x : v)
+            if (!std::isfinite(x) || (x == 0.0f && std::signbit(x))) return PTGPU_OK;
+        lo[i] = make_float4(b.lo.x, b.lo.y, b.lo.z, u2f(tris[i].id));
+        hi[i] = make_float4(b.hi.x, b.hi.y, b.hi.z, 0.0f);
+    }
+    DevBuf<float4> d_lo, d_hi, d_out;
+    DevBuf<BuildNode> d_nodes;
+    DevBuf<uint32_t> d_a, d_b, d_words;  // d_words: node counter, error flag
+    HIP_TRY(d_lo.upload(lo, c->stream));
+    HIP_TRY(d_hi.upload(hi, c->stream));
+    const uint32_t max_nodes = (uint32_t)(2 * n);
+    HIP_TRY(d_nodes.alloc(max_nodes));
+    HIP_TRY(d_a.alloc(n));
+    HIP_TRY(d_b.alloc(n));
+    HIP_TRY(d_words.alloc(2));
+    HIP_TRY(hipMemsetAsync(d_nodes.p, 0, (size_t)max_nodes * sizeof(BuildNode), c->stream));
+    BuildNode root{};
+    root.begin = 0;
+    root.end = (uint32_t)n;
+    uint32_t words[2] = {1u, 0u};
+    HIP_TRY(hipMemcpyAsync(d_nodes.p, &root, sizeof(root), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(d_words.p, words, sizeof(words), hipMemcpyHostToDevice, c->stream));
+    BuildArgs a{d_lo.p, d_hi.p, d_nodes.p, d_words.p, max_nodes, d_a.p, d_b.p, d_words.p + 1};
+    std::vector<std::pair<uint32_t, uint32_t>> levels;  // first node, nodes
+    uint32_t first = 0, count = 1;
+    while (count > 0) {
+        if (levels.size() > 4096) return PTGPU_OK;  // the host builder's recursion is what such a tree gets
+        levels.emplace_back(first, count);
+        hipLaunchKernelGGL(k_bvh_split, dim3(count), dim3(kBuildBlock), 0, c->stream, a, first);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(words, d_words.p, sizeof(words), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (words[1] != 0) return fail(PTGPU_E_DEVICE, "scene_create: device BVH build failed (internal error " + std::to_string(words[1]) + ")");
+        first += count;
+        count = words[0] - first;
+    }
+    const uint32_t n_nodes = words[0];
+    for (size_t l = levels.size(); l-- > 0;)
+        hipLaunchKernelGGL(k_bvh_count, dim3((levels[l].second + 255) / 256), dim3(256), 0, c->stream, d_nodes.p, levels[l].first, levels[l].second);
+    for (size_t l = 0; l < levels.size(); l++)
+        hipLaunchKernelGGL(k_bvh_number, dim3((levels[l].second + 255) / 256), dim3(256), 0, c->stream, d_nodes.p, levels[l].first, levels[l].second);
+    HIP_TRY(d_out.alloc(2 * (size_t)n_nodes));
+    hipLaunchKernelGGL(k_bvh_emit, dim3((n_nodes + 255) / 256), dim3(256), 0, c->stream, d_nodes.p, n_nodes, d_out.p, d_words.p + 1);
+    HIP_TRY(hipGetLastError());
+    std::vector<float4> flat(2 * (size_t)n_nodes);
+    HIP_TRY(hipMemcpyAsync(flat.data(), d_out.p, flat.size() * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(lo.data(), d_lo.p, n * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(hi.data(), d_hi.p, n * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(words, d_words.p, sizeof(words), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    built = true;
+    if (words[1] == 3) {
+        leaf_too_big = true;
+        return PTGPU_OK;
+    }
+    out.nodes.resize(n_nodes);
+    for (uint32_t i = 0; i < n_nodes; i++) {
+        const float4 l = flat[2 * (size_t)i], h = flat[2 * (size_t)i + 1];
+        const uint32_t meta = f2u(h.w);
+        out.nodes[i] = FlatNode{Box3{mk3(l.x, l.y, l.z), mk3(h.x, h.y, h.z)}, f2u(l.w), (uint16_t)(meta & 0xffffu), (uint8_t)(meta >> 16)};
+    }
+    out.leaf_order.resize(n);
+    for (size_t i = 0; i < n; i++) {
+        out.leaf_order[i] = f2u(lo[i].w);
+        tris[i] = BuildTri{Box3{mk3(lo[i].x, lo[i].y, lo[i].z), mk3(hi[i].x, hi[i].y, hi[i].z)}, f2u(lo[i].w)};
+    }
+    return PTGPU_OK;
+}
+}  // namespace
+
+int ptgpu_set_bvh_builder(ptgpu_ctx* c, int mode) {
+    if (!c || mode < 0 || mode > 2) return fail(PTGPU_E_INVALID, "set_bvh_builder: mode is 0 (host), 1 (device) or 2 (by scene size)");
+    c->bvh_builder = mode;
+    return PTGPU_OK;
+}
+int ptgpu_bvh_built_on_device(ptgpu_ctx* c) { return (c && c->have_scene && c->bvh_built_on_device) ? 1 : 0; }
+
 int ptgpu_scene_create(ptgpu_ctx* c, const ptgpu_scene_desc* desc) {
     if (!c || !desc || !desc->meshes || desc->n_meshes == 0) return fail(PTGPU_E_INVALID, "scene_create: empty description");
     HIP_TRY(hipSetDevice(c->device));
@@ -394,7 +488,14 @@ int ptgpu_scene_create(ptgpu_ctx* c, const ptgpu_scene_desc* desc) {
     }
     if (build.empty()) return fail(PTGPU_E_INVALID, "scene_create: no triangles");
     FlatBvh bvh;
-    if (!build_bvh(build, bvh)) return fail(PTGPU_E_LIMIT, "scene_create: a BVH leaf exceeds 65535 triangles");
+    bool on_device = false, leaf_too_big = false;
+    if (c->bvh_builder == 1 || (c->bvh_builder == 2 && build.size() >= kDeviceBuildFrom)) {
+        const int rc = build_bvh_device(c, build, bvh, on_device, leaf_too_big);
+        if (rc != PTGPU_OK) return rc;
+    }
+    if (!on_device) leaf_too_big = !build_bvh(build, bvh);
+    if (leaf_too_big) return fail(PTGPU_E_LIMIT, "scene_create: a BVH leaf exceeds 65535 triangles");
+    c->bvh_built_on_device = on_device;
 
     const size_t n_tris = bvh.leaf_order.size(), n_nodes = bvh.nodes.size();
     // deepest leaf: the traversal keeps at most one waiting sibling per level
