@@ -487,7 +487,11 @@ __global__ __launch_bounds__(kBlock, KINDS != 7 ? PT_PATH_DIFFUSE_WAVES : PT_SHA
                     }
                     const float u1d = rng_f32(rng), ua = rng_f32(rng), ub = rng_f32(rng);
                     BsdfSample bs;
-                    if (bsdf_sample(bsdf, sf.frame, sf.ng, wo, u1d, ua, ub, true, bs)) {
+                    // At the last bounce the reference still samples the BSDF, but nothing of the sample outlives the loop
+                    // (path_tracer.rs:160-181: beta, the ray and the pdf feed an iteration that `depth < max_depth` denies)
+                    // except terminate_secondary, which only a dielectric can raise: other surfaces skip the dead sample.
+                    const bool dead_sample = depth + 1 >= rp.max_depth && bsdf.kind != MAT_DIELECTRIC;
+                    if (!dead_sample && bsdf_sample(bsdf, sf.frame, sf.ng, wo, u1d, ua, ub, true, bs)) {
                         const float inv_pdf = bs.pdf;
 #pragma unroll
                         for (int k = 0; k < NSW; k++) beta.v[k] *= bs.f.v[k] / inv_pdf;
