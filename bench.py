@@ -276,6 +276,20 @@ def main() -> int:
             s_gbs = survey_bytes / args.steps / s_n / (s_ms / s_n * 1e-3) * 1e-9
             roofline["serialized"] = {"avg_launch_ms": round(s_ms / s_n, 4), "launches": int(s_n), "achieved": round(s_gbs, 2), "frac": round(s_gbs / HBM_PEAK_GBS, 5),
                                       "note": "same step with the record pass on the walk's stream (ptgpu_set_record_overlap(0)): the kernel alone on the GPU"}
+    # Informational, never the headline: the same render without recording the LAST wave's paths into the SD-tree, which the
+    # reference does (path_guiding/mod.rs:106-116) although nothing reads that tree again (ptgpu_set_final_training).
+    dead_training = None
+    if guided and world == 1:
+        ctx.set_final_training(False)
+        step(spp)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        step(spp)
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t0
+        ctx.set_final_training(True)
+        dead_training = {"value": round(resx * resy * spp / dt * 1e-6, 3), "unit": "Msamples/s", "ms_per_step": round(dt * 1e3, 3), "steps": 1,
+                         "note": "same image; the last wave's statistics, which feed nothing, are not gathered (ptgpu_set_final_training(0)); not the headline"}
     if census:
         n_ext, n_sh = max(1, st["extend_rays"]), max(1, st["shadow_rays"])
         roofline["census"] = {"nodes_per_extend_ray": round(census["extend_nodes"] / n_ext, 2), "tris_per_extend_ray": round(census["extend_tris"] / n_ext, 2),
@@ -329,6 +343,8 @@ def main() -> int:
     }
     if other:
         out["other_scaling"] = other
+    if dead_training:
+        out["without_final_training"] = dead_training
     sys.stdout.flush()
     os.write(result_fd, (json.dumps(out) + "\n").encode())
     if use_dist:

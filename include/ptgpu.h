@@ -229,6 +229,11 @@ int ptgpu_kernel_times(ptgpu_ctx* ctx, double* ms_out, uint64_t* launches_out, u
  * kernel has the GPU to itself (same results; about 1 % slower; per-kernel times that are the kernel's own). Initial
  * value: on, unless the environment variable PTGPU_NO_OVERLAP is set. No counterpart in the reference (measurement hook). */
 int ptgpu_set_record_overlap(ptgpu_ctx* ctx, int enabled);
+/* guided: the reference records every path of the LAST wave into the SD-tree as it does in the others
+ * (path_guiding/mod.rs:106-116), although nothing reads that tree again: the image and `stree.len()` (mod.rs:121) do not
+ * depend on it. 1 (the default) does the same; 0 leaves the last wave's statistics empty (ptgpu_guided_stats after the
+ * last wave then returns zeros) and renders the same image about 10 % sooner. bench.py's headline is measured with 1. */
+int ptgpu_set_final_training(ptgpu_ctx* ctx, int enabled);
 /* Traversal census for roofline accounting (bench only; selects instrumented kernel variants, off by default):
  * out[0..3] = BVH nodes visited / triangles tested by extend rays, then by occlusion rays, since it was enabled. */
 int ptgpu_set_census(ptgpu_ctx* ctx, int enabled);

@@ -91,6 +91,7 @@ PTGPU_SYMBOLS = [
     "ptgpu_trace_batch_noalloc", "ptgpu_guided_tree_info", "ptgpu_guided_tree_download", "ptgpu_guided_probe",
     "ptgpu_guided_record_batch", "ptgpu_guided_refine", "ptgpu_guard_counts", "ptgpu_film_device", "ptgpu_set_traversal",
     "ptgpu_get_traversal", "ptgpu_set_record_overlap", "ptgpu_set_bvh_builder", "ptgpu_bvh_built_on_device",
+    "ptgpu_set_final_training",
 ]
 PTHOST_SYMBOLS = [
     "pthost_last_error", "pthost_scene_load", "pthost_scene_free", "pthost_scene_desc", "pthost_camera_desc",
@@ -334,6 +335,11 @@ class Context:
     def bvh_built_on_device(self) -> bool:
         self.lib.ptgpu_bvh_built_on_device.argtypes = [C.c_void_p]
         return bool(self.lib.ptgpu_bvh_built_on_device(self.handle))
+
+    def set_final_training(self, on: bool):
+        """guided: record the last wave's paths into the SD-tree as the reference does (default), or skip that dead work."""
+        self.lib.ptgpu_set_final_training.argtypes = [C.c_void_p, C.c_int]
+        self._check(self.lib.ptgpu_set_final_training(self.handle, 1 if on else 0))
 
     def set_record_overlap(self, on: bool):
         """guided: record pass of one batch beside the walk of the next (default) or every kernel alone on the GPU."""

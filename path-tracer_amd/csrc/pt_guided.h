@@ -543,6 +543,7 @@ struct GuidedParams {
     uint32_t n_rows;       // max_depth + 1 vertex rows
     uint32_t row_stride;   // = capacity
     uint32_t write_film;   // only the last wave reaches the image (film.clear() per wave, mod.rs:80)
+    uint32_t record;       // 0: the scan only folds the paths into the film (ptgpu_set_final_training(0), last wave)
     uint32_t shard_index, shard_count;
     uint32_t tiles_x, n_tiles;
 };
@@ -986,7 +987,7 @@ __global__ __launch_bounds__(kBlock, PT_SCAN_WAVES) void k_guide_scan(SceneDev s
                 if (f2u(wi.w) & 2u) l = l + spec_from(cur[VTX_LI0], cur[VTX_LI1]);  // fields without their bit were never written
                 if (f2u(wi.w) & 1u) l = l + spec_from(cur[VTX_E0], cur[VTX_E1]);
             }
-            const unsigned long long m = __ballot(want);
+            const unsigned long long m = gp.record ? __ballot(want) : 0ull;
             if (m != 0ull) {
                 uint32_t wbase = 0;
                 if (lane == 0) wbase = atomicAdd(&sm_n, (uint32_t)__popcll(m));

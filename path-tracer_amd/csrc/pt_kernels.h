@@ -706,7 +706,8 @@ __global__ __launch_bounds__(kBlock, PT_SHADE_WAVES) void k_shade_light(SceneDev
                 Rng rng{(uint64_t)rp4.x | ((uint64_t)rp4.y << 32), rng_inc_for_pixel(rp4.z % rp.resx, rp4.z / rp.resx)};
                 const float u1d = rng_f32(rng), ua = rng_f32(rng), ub = rng_f32(rng);
                 BsdfSample bs;
-                if (bsdf_sample(bsdf, sf.frame, sf.ng, wo, u1d, ua, ub, false, bs)) {
+                // (the sample of the walk's last iteration feeds nothing, light_path_tracer.rs:100-117: skipped)
+                if (depth < rp.max_depth && bsdf_sample(bsdf, sf.frame, sf.ng, wo, u1d, ua, ub, false, bs)) {
                     const float pdf = bs.pdf;
 #pragma unroll
                     for (int k = 0; k < NSW; k++) beta.v[k] *= bs.f.v[k] / pdf;

@@ -170,6 +170,7 @@ struct ptgpu_ctx {
     GuidedPersist* guided_persist = nullptr;
     int bvh_builder = 2;               // ptgpu_set_bvh_builder: 0 host, 1 device, 2 device for scenes of kDeviceBuildFrom triangles and more
     bool bvh_built_on_device = false;  // how the resident scene's tree was built
+    bool train_last_wave = true;       // ptgpu_set_final_training
     bool direct_splat = false;         // PTGPU_DIRECT_SPLAT, sampled at the start of a wave
     bool record_overlap = getenv("PTGPU_NO_OVERLAP") == nullptr;  // guided: record pass on the second stream (ptgpu_set_record_overlap)
     bool film_ready = false;           // d_film_packed holds the film of the last completed render
@@ -779,6 +780,12 @@ int ptgpu_occluded_batch(ptgpu_ctx* c, const float* from, const float* to, uint3
 int ptgpu_set_profiling(ptgpu_ctx* c, int enabled) {
     if (!c) return fail(PTGPU_E_INVALID, "set_profiling: NULL ctx");
     c->profiling = enabled != 0;
+    return PTGPU_OK;
+}
+int ptgpu_set_final_training(ptgpu_ctx* c, int enabled) {
+    if (!c) return fail(PTGPU_E_INVALID, "set_final_training: NULL ctx");
+    if (c->guided) return fail(PTGPU_E_STATE, "set_final_training: not between guided_begin and guided_end");
+    c->train_last_wave = enabled != 0;
     return PTGPU_OK;
 }
 int ptgpu_set_record_overlap(ptgpu_ctx* c, int enabled) {

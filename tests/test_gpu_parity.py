@@ -411,6 +411,31 @@ def test_guided_record_pass_beside_or_behind_the_walk(gpu_ctx):
     assert abs((fa * sa).mean() / (fb * sb).mean() - 1.0) < 0.01
 
 
+def test_guided_without_the_last_wave_s_training(gpu_ctx):
+    """ptgpu_set_final_training(0): the last wave's paths are folded into the film but not recorded into the SD-tree (the
+    reference records them, mod.rs:106-116, and never reads the tree again). Same samples, same rays, same tree topology,
+    the same image up to what f32 atomic order does to two free-running renders; the statistics of the last wave stay empty."""
+    sc = pt.LoadedScene("cornell-box-guided", resx=64, resy=64, max_depth=8)
+    gpu_ctx.load(sc)
+    out = {}
+    try:
+        for on in (True, False):
+            gpu_ctx.set_final_training(on)
+            n = gpu_ctx.guided_begin(sc.integrator, 63)
+            for w in range(n):
+                gpu_ctx.guided_wave(w)
+            last_stats = gpu_ctx.guided_stats_host()
+            out[on] = (gpu_ctx.guided_end(), last_stats)
+    finally:
+        gpu_ctx.set_final_training(True)
+    ((fa, sa, sta), stats_a), ((fb, sb, stb), stats_b) = out[True], out[False]
+    assert stats_a.any() and not stats_b.any()
+    assert sa == sb and sta["samples"] == stb["samples"]
+    assert sta["stree_nodes"] == stb["stree_nodes"] and abs(sta["dtree_nodes"] - stb["dtree_nodes"]) <= 0.01 * sta["dtree_nodes"] + 8
+    assert abs(sta["extend_rays"] / stb["extend_rays"] - 1.0) < 2e-3
+    assert abs((fa * sa).mean() / (fb * sb).mean() - 1.0) < 0.01
+
+
 def test_guided_shards_cover_every_sample_once(gpu_ctx):
     sc = pt.LoadedScene("cornell-box-guided", resx=48, resy=40, max_depth=4)   # ragged tiles: 48x40 = 3x3 tiles, last row 8 high
     gpu_ctx.load(sc)
