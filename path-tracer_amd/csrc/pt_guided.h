@@ -1344,30 +1344,68 @@ __global__ __launch_bounds__(kBinBlock) void k_guide_splat_bins(SdTreeDev tree, 
 // parents first; what a node owes to a child's subtree is split in four, to that child's leaf cells directly and to
 // its interior children as their debt. Runs once per wave, after the last record pass and before the statistics
 // leave the device (ptgpu_guided_stats) or are refined.
+constexpr uint32_t kPushTreeLds = 256;  // nodes of a leaf's collector quadtree staged in LDS (larger trees are swept in global memory)
+constexpr uint32_t kPushWavePerLeafUpTo = 6144;  // leaves: beyond, one thread per leaf (LANES = 1) keeps more sweeps in flight (pt_refine.h)
+template <uint32_t LANES>
 __global__ __launch_bounds__(kBlock) void k_push_lazy(SdTreeDev t) {
-    const uint32_t leaf = blockIdx.x * blockDim.x + threadIdx.x;
+    // LANES = 64: one wave per spatial leaf: the tree goes to LDS, one lane sweeps it there, the wave writes it back (pt_refine.h)
+    struct Staged {
+        float4 rad[kPushTreeLds], lazy[kPushTreeLds];
+        uint2 child[kPushTreeLds];
+    };
+    __shared__ Staged sm[LANES == 64u ? kBlock / 64u : 1u];
+    const uint32_t leaf = LANES == 64u ? blockIdx.x * (kBlock / 64u) + threadIdx.x / 64u : blockIdx.x * kBlock + threadIdx.x, lane = LANES == 64u ? __lane_id() : 0u;
     if (leaf >= t.n_leaves) return;
+    Staged& st = sm[LANES == 64u ? threadIdx.x / 64u : 0u];
     const uint32_t base = t.leaf_info[leaf].y, n = t.c_size[leaf];
-    // interior children have larger indices than their parent and lie above kMaxQuadLevel (pt_refine.h:
-    // reshape_collector), so one sweep from the first node to the last sees every debt after it has been handed down
-    for (uint32_t i = 0; i < n; i++) {
-        const float4 z = t.c_lazy[base + i];
-        if (z.x == 0.0f && z.y == 0.0f && z.z == 0.0f && z.w == 0.0f) continue;
-        const uint2 links = t.c_child[base + i];
-        t.c_lazy[base + i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        const float owed[4] = {z.x, z.y, z.z, z.w};
-        for (int c = 0; c < 4; c++) {
-            const uint32_t link = child_link(links, c);
-            if (owed[c] == 0.0f || link <= i || link >= n) continue;
-            const float q = owed[c] * 0.25f;
-            const uint2 below = t.c_child[base + link];
-            float4 s = t.c_rad[base + link], d = t.c_lazy[base + link];
-            if (child_link(below, 0) == 0u) s.x += q; else d.x += q;
-            if (child_link(below, 1) == 0u) s.y += q; else d.y += q;
-            if (child_link(below, 2) == 0u) s.z += q; else d.z += q;
-            if (child_link(below, 3) == 0u) s.w += q; else d.w += q;
-            t.c_rad[base + link] = s;
-            t.c_lazy[base + link] = d;
+    const bool staged = LANES == 64u && n <= kPushTreeLds;
+    float4* rad = t.c_rad + base;
+    float4* lazy = t.c_lazy + base;
+    const uint2* child = t.c_child + base;
+    if (staged) {
+        bool any = false;
+        for (uint32_t i = lane; i < n; i += LANES) {
+            const float4 z = lazy[i];
+            st.lazy[i] = z;
+            st.rad[i] = rad[i];
+            st.child[i] = child[i];
+            any = any || z.x != 0.0f || z.y != 0.0f || z.z != 0.0f || z.w != 0.0f;
+        }
+        if (__ballot(any) == 0ull) return;  // nothing owed anywhere in this tree
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        rad = st.rad;
+        lazy = st.lazy;
+        child = st.child;
+    }
+    if (lane == 0) {
+        // interior children have larger indices than their parent and lie above kMaxQuadLevel (pt_refine.h:
+        // reshape_collector), so one sweep from the first node to the last sees every debt after it has been handed down
+        for (uint32_t i = 0; i < n; i++) {
+            const float4 z = lazy[i];
+            if (z.x == 0.0f && z.y == 0.0f && z.z == 0.0f && z.w == 0.0f) continue;
+            const uint2 links = child[i];
+            lazy[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            const float owed[4] = {z.x, z.y, z.z, z.w};
+            for (int c = 0; c < 4; c++) {
+                const uint32_t link = child_link(links, c);
+                if (owed[c] == 0.0f || link <= i || link >= n) continue;
+                const float q = owed[c] * 0.25f;
+                const uint2 below = child[link];
+                float4 s = rad[link], d = lazy[link];
+                if (child_link(below, 0) == 0u) s.x += q; else d.x += q;
+                if (child_link(below, 1) == 0u) s.y += q; else d.y += q;
+                if (child_link(below, 2) == 0u) s.z += q; else d.z += q;
+                if (child_link(below, 3) == 0u) s.w += q; else d.w += q;
+                rad[link] = s;
+                lazy[link] = d;
+            }
+        }
+    }
+    if (staged) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        for (uint32_t i = lane; i < n; i += LANES) {
+            t.c_rad[base + i] = st.rad[i];
+            t.c_lazy[base + i] = st.lazy[i];
         }
     }
 }
