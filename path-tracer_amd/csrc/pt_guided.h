@@ -906,6 +906,64 @@ __global__ __launch_bounds__(kBlock) void k_occlude_guided(SceneDev sc, GuidedPa
     if (CENSUS) census_add(census, 2, cn, ct);
 }
 
+// The two walkers of the guided integrator in ONE launch: the shadow rays of round r and the bounce rays of round r + 1
+// both exist once shade(r) has run and do not depend on each other. Late rounds and small waves (one GPU's share of a
+// multi-GPU job) are bound by launch count and by the tail of each launch, not by work: two launches per round instead of
+// three, and either walker's tail is filled by the other's workgroups. The grid is divided between the two roles in
+// proportion to their work (a bounce ray costs about twice a shadow ray); every workgroup derives the split from the
+// round's counters, so it needs no host look.
+#ifndef PT_WALK_WAVES
+#define PT_WALK_WAVES 7  // 8 (64 VGPRs) spills 28 B with both walkers' arguments live
+#endif
+template <bool CENSUS, bool WIDE>
+__global__ __launch_bounds__(kBlock, WIDE ? PT_WIDE_WAVES : PT_WALK_WAVES) void k_walk_guided(SceneDev sc, GuidedParams gp, PathCols st, HitCols hit, ShadowCols sh, const RoundCounters* cnt,
+                                                                               const uint32_t* top, uint32_t capacity, unsigned long long* census) {
+    const uint32_t n_bottom = cnt->n_active, n_ext = n_bottom + *top, n_sh = cnt->n_shadow;
+    const uint32_t G = gridDim.x;
+    uint32_t g_ext = 0;
+    if (n_ext != 0 && n_sh == 0) g_ext = G;
+    else if (n_ext != 0) {
+        const float share = 2.0f * (float)n_ext / (2.0f * (float)n_ext + (float)n_sh);
+        g_ext = (uint32_t)(share * (float)G + 0.5f);
+        g_ext = G > 1 ? (g_ext < 1u ? 1u : (g_ext > G - 1u ? G - 1u : g_ext)) : 1u;  // (a grid of one workgroup does both, below)
+    }
+    uint32_t cn = 0, ct = 0;
+    const bool both = G == 1 && n_ext != 0 && n_sh != 0;
+    const bool extend_role = blockIdx.x < g_ext;
+    if (extend_role || both) {
+        const uint32_t b = blockIdx.x, stride = g_ext * blockDim.x;
+        if (b * blockDim.x < n_ext) {
+            bvh_stage_nodes<WIDE>(sc);
+            for (uint32_t j = b * blockDim.x + threadIdx.x; j < n_ext; j += stride) {
+                const uint32_t i = slot_of_index(j, n_bottom, capacity);
+                float4 o = st.o_pdf[i], d = st.d_flags[i];
+                asm volatile("" : "+v"(o.x), "+v"(o.y), "+v"(o.z), "+v"(d.x), "+v"(d.y), "+v"(d.z));  // one load each (see bvh_intersect)
+                const Hit h = bvh_intersect<CENSUS, false, WIDE>(sc, mk3(o.x, o.y, o.z), mk3(d.x, d.y, d.z), f_inf(), &cn, &ct);
+                hit.tb[i] = make_float4(h.th.t, h.th.b0, h.th.b1, h.th.b2);
+                hit.prim[i] = make_uint2(h.prim, h.tag);
+            }
+            if (CENSUS) census_add(census, 0, cn, ct);
+        }
+        if (!both) return;
+        cn = ct = 0;
+        __syncthreads();
+    }
+    {
+        const uint32_t g_occ = both ? 1u : G - g_ext, b = both ? 0u : blockIdx.x - g_ext, stride = g_occ * blockDim.x;
+        if (b * blockDim.x >= n_sh) return;
+        bvh_stage_nodes<WIDE>(sc);
+        for (uint32_t j = b * blockDim.x + threadIdx.x; j < n_sh; j += stride) {
+            const float4 a = sh.q0[j], q = sh.q1[j];
+            if (scene_occluded<CENSUS, WIDE>(sc, mk3(a.x, a.y, a.z), mk3(q.x, q.y, q.z), &cn, &ct)) {
+                float4* v = gp.vtx.at(f2u(q.w), f2u(a.w));
+                v[VTX_LI0] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                v[VTX_LI1] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            }
+        }
+        if (CENSUS) census_add(census, 2, cn, ct);
+    }
+}
+
 // Back-to-front pass over each finished path (mod.rs:106-116): what arrives at a vertex from further along the path
 // is recorded into the SD-tree, then folded through the vertex. Two kernels:
 //   k_guide_scan  — one lane per path walks its vertices back to front (row v of all paths is contiguous), draws the
