@@ -261,7 +261,12 @@ PT_HD V3 offset_ray_origin_from(V3 p, V3 n, float mag, V3 w) {
     return po;
 }
 
-PT_HD V3 permute_kz(V3 v, int kz) { return kz == 0 ? mk3(v.y, v.z, v.x) : (kz == 1 ? mk3(v.z, v.x, v.y) : v); }
+// (component by component: as a choice between three whole vectors the compiler turns it into two nested branches with
+// register moves, ~17 instructions per vertex in the triangle loop where six selects do)
+PT_HD V3 permute_kz(V3 v, int kz) {
+    const bool k0 = kz == 0, k1 = kz == 1;
+    return mk3(k0 ? v.y : (k1 ? v.z : v.x), k0 ? v.z : (k1 ? v.x : v.y), k0 ? v.x : (k1 ? v.y : v.z));
+}
 PT_HD float diff_of_products(float a, float b, float c, float d) {  // geom.rs:195-200
     float cd = c * d;
     float dop = fmaf(a, b, -cd);
@@ -341,6 +346,11 @@ PT_HD bool ray_triangle(V3 ro, const RayShear& rs, V3 p0, V3 p1, V3 p2, float ma
     return true;
 }
 
+#ifdef PT_CENSUS_WAVE  // experiment: the census counts loop trips of the WAVE (one lane of those in the trip counts it)
+#define PT_CENSUS_LEAD ((int)__lane_id() == __ffsll((long long)__ballot(1)) - 1)
+#else
+#define PT_CENSUS_LEAD true
+#endif
 // ------------------------------------------------------------------ BVH traversal (pt/src/bvh.rs:86-146,306-327)
 // Node = two float4: {lo.xyz, bits(offset)}, {hi.xyz, bits(n_tris | split_axis << 16)}; interior nodes keep
 // their left child at index+1 and `offset` = right child. The visit order (far child pushed first, near on
@@ -404,7 +414,7 @@ PT_D bool bvh_test_leaf(const SceneDev& sc, V3 o, const RayShear& shear, float r
         // what bounds this loop. Passing the loaded values through an empty asm pins one 16-byte load each.
         // (Closest-hit walks only: the occlusion kernels carry more state and would drop to 7 waves per SIMD.)
         if (!ANY_HIT) asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(b.x), "+v"(b.y), "+v"(b.z), "+v"(c.x), "+v"(c.y), "+v"(c.z));
-        if (COUNT) (*n_tris_tested)++;
+        if (COUNT && PT_CENSUS_LEAD) (*n_tris_tested)++;
         TriHit th;
         if (ray_triangle(o, shear, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), best.th.t, th)) {
             best.th = th;
@@ -423,7 +433,11 @@ PT_D bool bvh_test_leaf(const SceneDev& sc, V3 o, const RayShear& shear, float r
 // of the same triangle bounds), and the slab test is monotone in the box (the products inv * (near - o) and
 // slack * inv * (far - o) are monotone in near and far for a fixed ray, a NaN from 0 * inf is ignored by fmaxf/fminf
 // exactly where the larger box gives -inf/+inf or NaN as well): a ray that passes the node's test passes every ancestor's.
-template <bool COUNT, bool ANY_HIT>
+// STAGED (nodes in LDS) is a template parameter, not a run-time choice of pointer: with `staged ? lds : global` the
+// compiler merges both reads into one FLAT load of a selected generic pointer, which sends the LDS reads through the
+// vector-memory front end (aperture check in the texture addresser, both wait counters) instead of ds_read_b128 and
+// the global ones through flat_load instead of global_load. bvh_intersect branches once per ray (uniform) instead.
+template <bool COUNT, bool ANY_HIT, bool STAGED>
 PT_D Hit bvh_intersect_wide(const SceneDev& sc, V3 o, V3 d, float ray_end_t, uint32_t* n_nodes_visited, uint32_t* n_tris_tested) {
     extern __shared__ uint32_t sm_bvh_stack[];
     uint32_t* stack = sm_bvh_stack + threadIdx.x;
@@ -440,7 +454,7 @@ PT_D Hit bvh_intersect_wide(const SceneDev& sc, V3 o, V3 d, float ray_end_t, uin
     const V3 sinv = mk3(slack * inv.x, slack * inv.y, slack * inv.z);
     const RayShear shear = ray_shear(d);
     uint32_t* pend = sm_bvh_stack + sc.wide_stack * kBlock + threadIdx.x;
-    const float4* nodes = sc.lds_wnodes ? reinterpret_cast<const float4*>(sm_bvh_stack + (sc.wide_stack + kLeafQueue) * kBlock) : sc.wnodes;
+    const float4* lds_nodes = reinterpret_cast<const float4*>(sm_bvh_stack + (sc.wide_stack + kLeafQueue) * kBlock);
     uint32_t sp = 0;
     uint32_t cur = 0;  // reference of the node or leaf to visit next (the root is wide node 0)
     bool have = true;
@@ -451,9 +465,14 @@ PT_D Hit bvh_intersect_wide(const SceneDev& sc, V3 o, V3 d, float ray_end_t, uin
                 pend[n_pend * kBlock] = cur;
                 n_pend++;
             } else {
-                const float4* wn = nodes + 8 * (size_t)cur;
-                const float4 lox = wn[0], loy = wn[1], loz = wn[2], hix = wn[3], hiy = wn[4], hiz = wn[5];
-                const float4 refs_f = wn[6], meta_f = wn[7];
+                float4 lox, loy, loz, hix, hiy, hiz, refs_f, meta_f;
+                if (STAGED) {
+                    const float4* wn = lds_nodes + 8 * cur;
+                    lox = wn[0], loy = wn[1], loz = wn[2], hix = wn[3], hiy = wn[4], hiz = wn[5], refs_f = wn[6], meta_f = wn[7];
+                } else {
+                    const float4* wn = sc.wnodes + 8 * (size_t)cur;
+                    lox = wn[0], loy = wn[1], loz = wn[2], hix = wn[3], hiy = wn[4], hiz = wn[5], refs_f = wn[6], meta_f = wn[7];
+                }
                 const uint32_t refs[4] = {f2u(refs_f.x), f2u(refs_f.y), f2u(refs_f.z), f2u(refs_f.w)};
                 const uint32_t table = octant < 4u ? f2u(meta_f.x) : f2u(meta_f.y);
                 const uint32_t perm = (table >> (8u * (octant & 3u))) & 0xffu, n_children = f2u(meta_f.z);
@@ -507,9 +526,8 @@ PT_D Hit bvh_intersect_wide(const SceneDev& sc, V3 o, V3 d, float ray_end_t, uin
     if (!ANY_HIT && best.prim != kNoHit) best.tag = f2u(sc.tri_v[3 * best.prim + 2].w);
     return best;
 }
-template <bool COUNT, bool ANY_HIT = false, bool WIDE = false>
-PT_D Hit bvh_intersect(const SceneDev& sc, V3 o, V3 d, float ray_end_t, uint32_t* n_nodes_visited, uint32_t* n_tris_tested) {
-    if (WIDE) return bvh_intersect_wide<COUNT, ANY_HIT>(sc, o, d, ray_end_t, n_nodes_visited, n_tris_tested);
+template <bool COUNT, bool ANY_HIT, bool STAGED>
+PT_D Hit bvh_intersect_binary(const SceneDev& sc, V3 o, V3 d, float ray_end_t, uint32_t* n_nodes_visited, uint32_t* n_tris_tested) {
     extern __shared__ uint32_t sm_bvh_stack[];
     uint32_t* stack = sm_bvh_stack + threadIdx.x;
     Hit best;
@@ -526,7 +544,6 @@ PT_D Hit bvh_intersect(const SceneDev& sc, V3 o, V3 d, float ray_end_t, uint32_t
     const RayShear shear = ray_shear(d);
     uint32_t* pend = sm_bvh_stack + sc.bvh_stack * kBlock + threadIdx.x;  // leaves waiting for their triangle tests
     const float4* lds_nodes = reinterpret_cast<const float4*>(sm_bvh_stack + (sc.bvh_stack + 2 * kLeafQueue) * kBlock);
-    const bool staged = sc.lds_nodes != 0;
     uint32_t sp = 0;
     uint32_t ni = 0;
     bool have_node = true;
@@ -534,7 +551,7 @@ PT_D Hit bvh_intersect(const SceneDev& sc, V3 o, V3 d, float ray_end_t, uint32_t
         uint32_t n_pend = 0;
         while (have_node && n_pend < kLeafQueue) {
             float4 n0, n1;
-            if (staged) {
+            if (STAGED) {
                 n0 = lds_nodes[2 * ni];
                 n1 = lds_nodes[2 * ni + 1];
             } else {
@@ -542,7 +559,7 @@ PT_D Hit bvh_intersect(const SceneDev& sc, V3 o, V3 d, float ray_end_t, uint32_t
                 n1 = sc.nodes[2 * ni + 1];
             }
             const uint32_t offset = f2u(n0.w), meta = f2u(n1.w);
-            if (COUNT) (*n_nodes_visited)++;
+            if (COUNT && PT_CENSUS_LEAD) (*n_nodes_visited)++;
             float tmin = 0.0f, tmax = ray_end_t, t_dom;
             {
                 float near_x = nx ? n1.x : n0.x, far_x = nx ? n0.x : n1.x;
@@ -593,7 +610,7 @@ PT_D Hit bvh_intersect(const SceneDev& sc, V3 o, V3 d, float ray_end_t, uint32_t
                 // what bounds this loop. Passing the loaded values through an empty asm pins one 16-byte load each.
                 // (Closest-hit walks only: the occlusion kernels carry more state and would drop to 7 waves per SIMD.)
                 if (!ANY_HIT) asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(b.x), "+v"(b.y), "+v"(b.z), "+v"(c.x), "+v"(c.y), "+v"(c.z));
-                if (COUNT) (*n_tris_tested)++;
+                if (COUNT && PT_CENSUS_LEAD) (*n_tris_tested)++;
                 TriHit th;
                 if (ray_triangle(o, shear, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), best.th.t, th)) {
                     best.th = th;
@@ -607,6 +624,15 @@ PT_D Hit bvh_intersect(const SceneDev& sc, V3 o, V3 d, float ray_end_t, uint32_t
     // fetched once per ray here rather than carried through the walk (a register the loop does not have to spare)
     if (!ANY_HIT && best.prim != kNoHit) best.tag = f2u(sc.tri_v[3 * best.prim + 2].w);
     return best;
+}
+template <bool COUNT, bool ANY_HIT = false, bool WIDE = false>
+PT_D Hit bvh_intersect(const SceneDev& sc, V3 o, V3 d, float ray_end_t, uint32_t* n_nodes_visited, uint32_t* n_tris_tested) {
+    if (WIDE) {
+        if (sc.lds_wnodes) return bvh_intersect_wide<COUNT, ANY_HIT, true>(sc, o, d, ray_end_t, n_nodes_visited, n_tris_tested);
+        return bvh_intersect_wide<COUNT, ANY_HIT, false>(sc, o, d, ray_end_t, n_nodes_visited, n_tris_tested);
+    }
+    if (sc.lds_nodes) return bvh_intersect_binary<COUNT, ANY_HIT, true>(sc, o, d, ray_end_t, n_nodes_visited, n_tris_tested);
+    return bvh_intersect_binary<COUNT, ANY_HIT, false>(sc, o, d, ray_end_t, n_nodes_visited, n_tris_tested);
 }
 // Scene::occluded (scene.rs:229-235): unnormalised segment, t_max 0.9999; only the boolean leaves this function.
 template <bool COUNT = false, bool WIDE = false>

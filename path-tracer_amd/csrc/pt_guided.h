@@ -1323,7 +1323,12 @@ PT_D void dtree_record_box_lane(const uint2* links_of, float* sums_of, float* la
     push(0u, Cell{0, 0, 0});
     while (sp > 0) {
         --sp;
-        const uint2 w = sp < (int)kBinStackLds ? make_uint2(lds_stack[(2 * sp) * kBinBlock], lds_stack[(2 * sp + 1) * kBinBlock]) : spill[(size_t)(sp - (int)kBinStackLds) * spill_stride];
+        // (the LDS read is unconditional and the rare spilled entry overrides it: as a choice between the two the
+        // compiler selects the POINTER and issues flat loads, slower than ds_read, on every pop)
+        const int sp_lds = sp < (int)kBinStackLds ? sp : (int)kBinStackLds - 1;
+        uint2 w = make_uint2(lds_stack[(2 * sp_lds) * kBinBlock], lds_stack[(2 * sp_lds + 1) * kBinBlock]);
+        asm volatile("" : "+v"(w.x), "+v"(w.y));  // (pins the ds_read: otherwise the two loads are sunk into one flat load all the same)
+        if (sp >= (int)kBinStackLds) w = spill[(size_t)(sp - (int)kBinStackLds) * spill_stride];
         const uint32_t sx = w.y & 0xffffffu, level = 31u - (uint32_t)__clz((int)sx);
         const uint32_t node = w.x & 0xffffu, ix = sx ^ (1u << level), iy = (w.x >> 16) | ((w.y >> 24) << 16);
         const uint2 links = links_of[node];
@@ -1417,27 +1422,10 @@ __global__ __launch_bounds__(kBlock) void k_push_lazy(SdTreeDev t) {
     Staged& st = sm[LANES == 64u ? threadIdx.x / 64u : 0u];
     const uint32_t base = t.leaf_info[leaf].y, n = t.c_size[leaf];
     const bool staged = LANES == 64u && n <= kPushTreeLds;
-    float4* rad = t.c_rad + base;
-    float4* lazy = t.c_lazy + base;
-    const uint2* child = t.c_child + base;
-    if (staged) {
-        bool any = false;
-        for (uint32_t i = lane; i < n; i += LANES) {
-            const float4 z = lazy[i];
-            st.lazy[i] = z;
-            st.rad[i] = rad[i];
-            st.child[i] = child[i];
-            any = any || z.x != 0.0f || z.y != 0.0f || z.z != 0.0f || z.w != 0.0f;
-        }
-        if (__ballot(any) == 0ull) return;  // nothing owed anywhere in this tree
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        rad = st.rad;
-        lazy = st.lazy;
-        child = st.child;
-    }
-    if (lane == 0) {
-        // interior children have larger indices than their parent and lie above kMaxQuadLevel (pt_refine.h:
-        // reshape_collector), so one sweep from the first node to the last sees every debt after it has been handed down
+    // interior children have larger indices than their parent and lie above kMaxQuadLevel (pt_refine.h:
+    // reshape_collector), so one sweep from the first node to the last sees every debt after it has been handed down
+    // (instantiated for the LDS copy and for global memory: see k_refine_sums)
+    auto sweep = [n](float4* rad, float4* lazy, const uint2* child) {
         for (uint32_t i = 0; i < n; i++) {
             const float4 z = lazy[i];
             if (z.x == 0.0f && z.y == 0.0f && z.z == 0.0f && z.w == 0.0f) continue;
@@ -1458,14 +1446,26 @@ __global__ __launch_bounds__(kBlock) void k_push_lazy(SdTreeDev t) {
                 lazy[link] = d;
             }
         }
-    }
+    };
     if (staged) {
+        bool any = false;
+        for (uint32_t i = lane; i < n; i += LANES) {
+            const float4 z = t.c_lazy[base + i];
+            st.lazy[i] = z;
+            st.rad[i] = t.c_rad[base + i];
+            st.child[i] = t.c_child[base + i];
+            any = any || z.x != 0.0f || z.y != 0.0f || z.z != 0.0f || z.w != 0.0f;
+        }
+        if (__ballot(any) == 0ull) return;  // nothing owed anywhere in this tree
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 0) sweep(st.rad, st.lazy, st.child);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         for (uint32_t i = lane; i < n; i += LANES) {
             t.c_rad[base + i] = st.rad[i];
             t.c_lazy[base + i] = st.lazy[i];
         }
-    }
+    } else if (lane == 0)
+        sweep(t.c_rad + base, t.c_lazy + base, t.c_child + base);
 }
 
 }  // namespace pt

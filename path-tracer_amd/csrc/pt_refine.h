@@ -49,9 +49,19 @@ PT_D float sum4(float4 r) { return (((0.0f + r.x) + r.y) + r.z) + r.w; }
 constexpr uint32_t kWavePerLeafUpTo = 6144;
 constexpr uint32_t kLeafTreeLds = 256;
 constexpr uint32_t kLeavesPerBlock = kBlock / 64u;
+struct ReshapeItem {  // walk stack of reshape_collector
+    uint32_t src_out;  // source node (0xffff = a cell split in this pass) | output index << 16
+    float quarter;     // for a split cell: the value each of its four children starts with
+    uint32_t depth;
+};
+constexpr int kReshapeStack = 3 * kMaxQuadLevel + 16;
 struct LeafTreeLds {
     float4 rad[kLeafTreeLds];
     uint2 child[kLeafTreeLds];
+};
+struct LeafWalkLds {  // k_refine_emit_count / k_refine_write, one wave per leaf: the tree and the walk's stack (private
+    LeafTreeLds tree;  // memory otherwise: 1 KB per lane of scratch, each push and pop a trip to memory)
+    ReshapeItem stack[kReshapeStack];
 };
 PT_D void wave_sync_lds() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }  // LDS traffic of one wave is in order; this keeps the compiler in line too
 
@@ -66,18 +76,9 @@ __global__ __launch_bounds__(kBlock) void k_refine_sums(RefineArgs a) {
     LeafTreeLds& t = sm[LANES == 64u ? threadIdx.x / 64u : 0u];
     const uint32_t base = a.old_off[leaf], n = a.old_size[leaf];
     const bool staged = LANES == 64u && n <= kLeafTreeLds;
-    float4* rad = a.old_rad + base;
-    const uint2* child = a.old_child + base;
-    if (staged) {
-        for (uint32_t i = lane; i < n; i += LANES) {
-            t.rad[i] = rad[i];
-            t.child[i] = child[i];
-        }
-        wave_sync_lds();
-        rad = t.rad;
-        child = t.child;
-    }
-    if (lane == 0) {
+    // (the sweep is instantiated once for the LDS copy and once for global memory: through one pointer that may be
+    // either, every access would be a FLAT one, slower than ds_read / global_load, on the serial chain)
+    auto sweep = [n](float4* rad, const uint2* child) {
         for (uint32_t i = n; i-- > 0;) {
             const uint2 links = child[i];
             if ((links.x | links.y) == 0u) continue;  // four leaf cells
@@ -89,11 +90,18 @@ __global__ __launch_bounds__(kBlock) void k_refine_sums(RefineArgs a) {
             if (l3 > i && l3 < n) r.w = sum4(rad[l3]);
             rad[i] = r;
         }
-    }
+    };
     if (staged) {
+        for (uint32_t i = lane; i < n; i += LANES) {
+            t.rad[i] = a.old_rad[base + i];
+            t.child[i] = a.old_child[base + i];
+        }
+        wave_sync_lds();
+        if (lane == 0) sweep(t.rad, t.child);
         wave_sync_lds();
         for (uint32_t i = lane; i < n; i += LANES) a.old_rad[base + i] = t.rad[i];
-    }
+    } else if (lane == 0)
+        sweep(a.old_rad + base, a.old_child + base);
 }
 
 // DTree::subdivide_and_clear (dtree.rs:291-324) as a pure function of the summed tree: drop subtrees that carry less
@@ -102,13 +110,8 @@ __global__ __launch_bounds__(kBlock) void k_refine_sums(RefineArgs a) {
 // zero: the caller clears the new statistics buffer). Output numbering: a node's interior children get consecutive
 // indices when the node is expanded.
 template <bool WRITE>
-PT_D uint32_t reshape_collector(const RefineArgs& a, const float4* src_rad, const uint2* src_child, uint32_t new_base) {
-    struct Item {
-        uint32_t src_out;  // source node (0xffff = a cell split in this pass) | output index << 16
-        float quarter;     // for a split cell: the value each of its four children starts with
-        uint32_t depth;
-    };
-    Item stack[3 * kMaxQuadLevel + 16];
+PT_D uint32_t reshape_collector(const RefineArgs& a, const float4* src_rad, const uint2* src_child, uint32_t new_base, ReshapeItem* stack) {
+    using Item = ReshapeItem;
     int sp = 0;
     const float total = sum4(src_rad[0]);
     uint32_t counter = 1;
@@ -145,7 +148,7 @@ PT_D uint32_t reshape_collector(const RefineArgs& a, const float4* src_rad, cons
             const uint32_t child_out = counter++;
             out_link[c] = child_out;
             const uint32_t link = src != 0xffffu ? child_link(links, c) : 0u;
-            if (sp < (int)(sizeof(stack) / sizeof(stack[0])))
+            if (sp < kReshapeStack)
                 stack[sp++] = link == 0u ? Item{0xffffu | (child_out << 16), r[c] / 4.0f, it.depth + 1u} : Item{link | (child_out << 16), 0.0f, it.depth + 1u};
             else
                 *a.error_flag = 2u;
@@ -158,10 +161,11 @@ PT_D uint32_t reshape_collector(const RefineArgs& a, const float4* src_rad, cons
 // Per NEW leaf: the sampling copy (emit_into), whether that copy's mean is zero, and the size of the reshaped collector.
 template <uint32_t LANES>
 __global__ __launch_bounds__(kBlock) void k_refine_emit_count(RefineArgs a) {
-    __shared__ LeafTreeLds sm[LANES == 64u ? kLeavesPerBlock : 1u];
+    __shared__ LeafWalkLds sm[LANES == 64u ? kLeavesPerBlock : 1u];
     const uint32_t leaf = LANES == 64u ? blockIdx.x * kLeavesPerBlock + threadIdx.x / 64u : blockIdx.x * kBlock + threadIdx.x, lane = LANES == 64u ? __lane_id() : 0u;
     if (leaf >= a.n_new_leaves) return;
-    LeafTreeLds& t = sm[LANES == 64u ? threadIdx.x / 64u : 0u];
+    LeafTreeLds& t = sm[LANES == 64u ? threadIdx.x / 64u : 0u].tree;
+    ReshapeItem* lds_stack = sm[LANES == 64u ? threadIdx.x / 64u : 0u].stack;
     const uint32_t src = a.src_leaf[leaf];
     const uint32_t ob = a.old_off[src], n = a.old_size[src], sb = a.s_off[leaf];
     const bool staged = LANES == 64u && n <= kLeafTreeLds;
@@ -176,22 +180,26 @@ __global__ __launch_bounds__(kBlock) void k_refine_emit_count(RefineArgs a) {
     }
     wave_sync_lds();
     if (lane != 0) return;
-    const float4* rad = staged ? t.rad : a.old_rad + ob;
-    const uint2* child = staged ? t.child : a.old_child + ob;
     float weight = a.old_weight[src];
     for (uint32_t k = 0; k < a.halvings[leaf]; k++) weight /= 2.0f;  // STree split: collector weight halves (stree.rs:55-101)
     // DTree::mean() == 0 (dtree.rs:71-77) decides between uniform and tree sampling
-    const float mean = weight == 0.0f ? 0.0f : sum4(rad[0]) / (kFourPi * weight);
-    a.new_size[leaf] = reshape_collector<false>(a, rad, child, 0u);
+    const float mean = weight == 0.0f ? 0.0f : sum4(a.old_rad[ob]) / (kFourPi * weight);
+    if (staged) a.new_size[leaf] = reshape_collector<false>(a, t.rad, t.child, 0u, lds_stack);  // (separate instances: see k_refine_sums)
+    else if (LANES == 64u) a.new_size[leaf] = reshape_collector<false>(a, a.old_rad + ob, a.old_child + ob, 0u, lds_stack);
+    else {
+        ReshapeItem stack[kReshapeStack];
+        a.new_size[leaf] = reshape_collector<false>(a, a.old_rad + ob, a.old_child + ob, 0u, stack);
+    }
     a.leaf_info[leaf] = make_uint4(sb, 0u, mean == 0.0f ? 1u : 0u, f2u(weight));  // w: the sampling copy's statistical weight (parity hooks)
 }
 
 template <uint32_t LANES>
 __global__ __launch_bounds__(kBlock) void k_refine_write(RefineArgs a) {
-    __shared__ LeafTreeLds sm[LANES == 64u ? kLeavesPerBlock : 1u];
+    __shared__ LeafWalkLds sm[LANES == 64u ? kLeavesPerBlock : 1u];
     const uint32_t leaf = LANES == 64u ? blockIdx.x * kLeavesPerBlock + threadIdx.x / 64u : blockIdx.x * kBlock + threadIdx.x, lane = LANES == 64u ? __lane_id() : 0u;
     if (leaf >= a.n_new_leaves) return;
-    LeafTreeLds& t = sm[LANES == 64u ? threadIdx.x / 64u : 0u];
+    LeafTreeLds& t = sm[LANES == 64u ? threadIdx.x / 64u : 0u].tree;
+    ReshapeItem* lds_stack = sm[LANES == 64u ? threadIdx.x / 64u : 0u].stack;
     const uint32_t src = a.src_leaf[leaf];
     const uint32_t ob = a.old_off[src], n = a.old_size[src];
     const bool staged = LANES == 64u && n <= kLeafTreeLds;
@@ -204,7 +212,12 @@ __global__ __launch_bounds__(kBlock) void k_refine_write(RefineArgs a) {
     }
     if (lane != 0) return;
     const uint32_t nb = a.new_off[leaf];
-    (void)reshape_collector<true>(a, staged ? t.rad : a.old_rad + ob, staged ? t.child : a.old_child + ob, nb);
+    if (staged) (void)reshape_collector<true>(a, t.rad, t.child, nb, lds_stack);
+    else if (LANES == 64u) (void)reshape_collector<true>(a, a.old_rad + ob, a.old_child + ob, nb, lds_stack);
+    else {
+        ReshapeItem stack[kReshapeStack];
+        (void)reshape_collector<true>(a, a.old_rad + ob, a.old_child + ob, nb, stack);
+    }
     a.leaf_info[leaf].y = nb;
 }
 

@@ -11,5 +11,10 @@ rows = [r for r in csv.DictReader(open(sys.argv[1])) if sys.argv[2] in r["Kernel
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows]
 half = len(d) // 2
-print(sys.argv[2], "us:", [round(x) for x in d[half:]], "sum", round(sum(d[half:])))
+d = d[half:]
+if len(d) > 40:
+    big = [x for x in d if x >= 1000]; mid = [x for x in d if 100 <= x < 1000]; small = [x for x in d if x < 100]
+    print(sys.argv[2], f"launches {len(d)} sum {sum(d) / 1e3:.1f} ms; >=1 ms: {len(big)} sum {sum(big) / 1e3:.1f}; 0.1-1 ms: {len(mid)} sum {sum(mid) / 1e3:.1f}; <0.1 ms: {len(small)} sum {sum(small) / 1e3:.1f}")
+else:
+    print(sys.argv[2], "us:", [round(x) for x in d], "sum", round(sum(d)))
 PY
