@@ -408,7 +408,8 @@ PT_D void bvh_stage_nodes(const SceneDev& sc) {
 template <bool COUNT, bool ANY_HIT>
 PT_D bool bvh_test_leaf(const SceneDev& sc, V3 o, const RayShear& shear, float ray_end_t, uint32_t leaf_first, uint32_t leaf_n, Hit& best, uint32_t* n_tris_tested) {
     for (uint32_t k = leaf_first; k < leaf_first + leaf_n; k++) {
-        float4 a = sc.tri_v[3 * k], b = sc.tri_v[3 * k + 1], c = sc.tri_v[3 * k + 2];
+        const float4* tv = sc.tri_v + 3 * (size_t)k;  // one address, two immediate offsets
+        float4 a = tv[0], b = tv[1], c = tv[2];
         // Left alone, the compiler re-loads overlapping halves of each vertex (x,y and y,z, for its packed-math
         // pairings): six vector-memory instructions per triangle instead of three, and vector-memory issue is
         // what bounds this loop. Passing the loaded values through an empty asm pins one 16-byte load each.
@@ -552,11 +553,13 @@ PT_D Hit bvh_intersect_binary(const SceneDev& sc, V3 o, V3 d, float ray_end_t, u
         while (have_node && n_pend < kLeafQueue) {
             float4 n0, n1;
             if (STAGED) {
-                n0 = lds_nodes[2 * ni];
-                n1 = lds_nodes[2 * ni + 1];
+                const float4* np = lds_nodes + 2 * ni;
+                n0 = np[0];
+                n1 = np[1];
             } else {
-                n0 = sc.nodes[2 * ni];
-                n1 = sc.nodes[2 * ni + 1];
+                const float4* np = sc.nodes + 2 * (size_t)ni;
+                n0 = np[0];
+                n1 = np[1];
             }
             const uint32_t offset = f2u(n0.w), meta = f2u(n1.w);
             if (COUNT && PT_CENSUS_LEAD) (*n_nodes_visited)++;
@@ -604,7 +607,8 @@ PT_D Hit bvh_intersect_binary(const SceneDev& sc, V3 o, V3 d, float ray_end_t, u
         for (uint32_t j = 0; j < n_pend; j++) {
             const uint32_t leaf_first = pend[(2 * j) * kBlock], leaf_n = pend[(2 * j + 1) * kBlock];
             for (uint32_t k = leaf_first; k < leaf_first + leaf_n; k++) {
-                float4 a = sc.tri_v[3 * k], b = sc.tri_v[3 * k + 1], c = sc.tri_v[3 * k + 2];
+                const float4* tv = sc.tri_v + 3 * (size_t)k;  // one address, two immediate offsets
+                float4 a = tv[0], b = tv[1], c = tv[2];
                 // Left alone, the compiler re-loads overlapping halves of each vertex (x,y and y,z, for its packed-math
                 // pairings): six vector-memory instructions per triangle instead of three, and vector-memory issue is
                 // what bounds this loop. Passing the loaded values through an empty asm pins one 16-byte load each.
