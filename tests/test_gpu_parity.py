@@ -252,6 +252,25 @@ def test_guided_ragged_image_first_wave_and_sample_count(gpu_ctx):
     assert abs((gf * gs).mean() / (cf * cs).mean() - 1.0) < 0.1
 
 
+@pytest.mark.parametrize("res", [(16, 16), (12, 9)])
+def test_guided_batches_of_one_workgroup(gpu_ctx, res):
+    """An image of one 16 x 16 tile: every launch is a single workgroup, and in k_walk_guided (occlusion of round r and
+    extension of round r + 1 in one launch) that one workgroup plays both roles in turn. Wave 0 against the oracle path
+    for path, ray counts of a 3-spp render (waves of 1 and 2 passes) equal."""
+    sc = pt.LoadedScene("cornell-box-guided", resx=res[0], resy=res[1], max_depth=6)
+    o = ob.OracleScene(sc)
+    gpu_ctx.load(sc)
+    gf, gs, gst = gpu_ctx.render(sc.integrator, 1)
+    cf, cs, cst = o.render(sc.camera, sc.integrator, 1)
+    rel = np.abs(gf - cf).sum(axis=2) / (np.abs(cf).sum(axis=2) + 1e-6)
+    assert (rel < 1e-3).mean() > 0.98
+    assert gst["extend_rays"] == cst["extend_rays"] and gst["shadow_rays"] == cst["shadow_rays"]
+    gf, gs, gst = gpu_ctx.render(sc.integrator, 3)
+    cf, cs, cst = o.render(sc.camera, sc.integrator, 3)
+    assert gst["samples"] == cst["samples"] == res[0] * res[1] * 3
+    assert abs((gf * gs).mean() / (cf * cs).mean() - 1.0) < 0.25
+
+
 def test_scene_without_emitters_renders_black(gpu_ctx):
     """No light to pick (Scene::choose_light returns None, scene.rs:257-268): every integrator returns a black film
     and traces the rays the oracle traces."""
