@@ -100,6 +100,7 @@ def main() -> int:
     ap.add_argument("--spp", type=int, default=0, help="override the workload's spp")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--census", action="store_true", help="also count BVH nodes/triangles per ray (extra untimed render)")
+    ap.add_argument("--timed-only", action="store_true", help="nothing but warm-up and timed steps (no serialized / census / image-check legs): what the counter passes of tools/gpu_traffic.sh run, so that their per-launch averages are over the timed region's launches only")
     ap.add_argument("--dry-run", action="store_true", help="launcher / process-group rehearsal only, no render (runs without a GPU)")
     args = ap.parse_args()
 
@@ -233,7 +234,7 @@ def main() -> int:
     my = {k: st[k] * args.steps for k in ("segments", "extend_rays", "shadow_rays", "samples")}
     survey_bytes, layout_bytes = stage_bytes(dom, guided, light, my["segments"], my["extend_rays"], my["shadow_rays"], my["samples"])
     census = None
-    if world == 1 and (args.census or dom in ("extend", "occlude")):
+    if world == 1 and not args.timed_only and (args.census or dom in ("extend", "occlude")):
         ctx.set_census(True)   # instrumented kernel variants, one extra untimed render
         step(spp)
         census = ctx.census()
@@ -265,7 +266,7 @@ def main() -> int:
     # The record pass of one batch runs beside the walk of the next (second stream): a kernel's launch duration in the timed
     # region is therefore its time on a SHARED GPU. One more, untimed, step with the streams serialised gives the dominant
     # kernel's duration with the GPU to itself (what a roofline fraction of the kernel means); reported beside, never instead.
-    if guided and world == 1:
+    if guided and world == 1 and not args.timed_only:
         ctx.set_record_overlap(False)
         ctx.set_profiling(True)
         step(spp)
@@ -279,7 +280,7 @@ def main() -> int:
     # Informational, never the headline: the same render without recording the LAST wave's paths into the SD-tree, which the
     # reference does (path_guiding/mod.rs:106-116) although nothing reads that tree again (ptgpu_set_final_training).
     dead_training = None
-    if guided and world == 1:
+    if guided and world == 1 and not args.timed_only:
         ctx.set_final_training(False)
         step(spp)
         torch.cuda.synchronize(dev)
@@ -302,7 +303,7 @@ def main() -> int:
 
     # ---- CPU baseline: the oracle (a port of the reference's algorithm), bounded sample, rank 0 at N=1 only
     cpu = None
-    if world == 1 and not args.no_cpu_baseline:
+    if world == 1 and not args.no_cpu_baseline and not args.timed_only:
         import oracle_bind as ob
         cores = min(16, os.cpu_count() or 1)
         cpu_spp = {"guided": 31, "path": 16, "veach-mis": 8, "lightpath": 16, "guided-large": 3, "guided-bidir": 7}[args.workload]
@@ -320,7 +321,7 @@ def main() -> int:
     relmse = None
     gold = REPO / "tests" / "golden" / "converged_cornell_64.npz"
     key = {"guided": "guided", "path": "path", "lightpath": "lightpath"}.get(args.workload)
-    if world == 1 and key and gold.exists():
+    if world == 1 and key and gold.exists() and not args.timed_only:
         g = np.load(gold)
         small = pt.LoadedScene(scene_name, resx=64, resy=64, max_depth=16, integrator=integrator)
         ctx.load(small)

@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 for C in FETCH_SIZE WRITE_SIZE; do
   OUT=$GRAFT_REPO_ROOT/gpurun_out/traffic_${TAG}_$C
   mkdir -p $OUT
-  timeout -s KILL 300 rocprofv3 --pmc $C --output-format csv -d $OUT -o pmc -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline "$@" > $OUT/bench.json 2> $OUT/bench.err || { tail -20 $OUT/bench.err; exit 1; }
+  timeout -s KILL 300 rocprofv3 --pmc $C --output-format csv -d $OUT -o pmc -- python3 bench.py --steps 1 --warmup 0 --timed-only "$@" > $OUT/bench.json 2> $OUT/bench.err || { tail -20 $OUT/bench.err; exit 1; }
 done
 python3 - "$TAG" <<'PY'
 import csv, sys, json, glob, collections, os
