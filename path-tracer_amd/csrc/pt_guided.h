@@ -1408,7 +1408,7 @@ __global__ __launch_bounds__(kBinBlock) void k_guide_splat_bins(SdTreeDev tree, 
 // its interior children as their debt. Runs once per wave, after the last record pass and before the statistics
 // leave the device (ptgpu_guided_stats) or are refined.
 constexpr uint32_t kPushTreeLds = 256;  // nodes of a leaf's collector quadtree staged in LDS (larger trees are swept in global memory)
-constexpr uint32_t kPushWavePerLeafUpTo = 6144;  // leaves: beyond, one thread per leaf (LANES = 1) keeps more sweeps in flight (pt_refine.h)
+constexpr uint32_t kPushWavePerLeafUpTo = 49152;  // leaves: beyond, one thread per leaf (LANES = 1) keeps more sweeps in flight (pt_refine.h)
 template <uint32_t LANES>
 __global__ __launch_bounds__(kBlock) void k_push_lazy(SdTreeDev t) {
     // LANES = 64: one wave per spatial leaf: the tree goes to LDS, one lane sweeps it there, the wave writes it back (pt_refine.h)

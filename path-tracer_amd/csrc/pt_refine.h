@@ -43,10 +43,12 @@ PT_D float sum4(float4 r) { return (((0.0f + r.x) + r.y) + r.z) + r.w; }
 // ms per kernel however small the wave: 5 ms per render, a per-rank constant of a multi-GPU job). The wave first copies
 // the leaf's tree into LDS, 64 nodes at a time, the serial walk then runs on LDS, and the wave writes the result back.
 // Trees larger than kLeafTreeLds nodes (the 1 % subdivision threshold keeps them near 10^2) are walked in global memory.
-// That pays while the leaves are few: beyond ~6 000 leaves (kWavePerLeafUpTo) one THREAD per leaf (LANES = 1, no staging)
-// keeps more walks in flight than one wave per leaf does and is the faster form (measured per wave of the headline:
-// 0.45 against 0.80 ms at 4 418 leaves, 0.83 against 0.81 at 6 312, 2.0 against 0.94 at 15 832).
-constexpr uint32_t kWavePerLeafUpTo = 6144;
+// That pays while the leaves are few: beyond a kernel's threshold one THREAD per leaf (LANES = 1, no staging) keeps more
+// walks in flight than one wave per leaf does. Measured per wave of the headline (microseconds, wave per leaf against
+// thread per leaf, at 4 418 / 6 312 / 8 814 / 11 881 / 15 833 leaves): sums 24-52 against 176-193 (a thread's walk is
+// ~120 dependent round trips to memory however few the leaves); lazy push 37-75 against 36-257; sampling copy + count
+// 142 / 165 / 208 / 253 against 253 / 249 / 272 / 271; reshape + write 140 / 170 / 222 / 273 against 158 / 158 / 162 / 182.
+constexpr uint32_t kSumsWavePerLeafUpTo = 49152, kEmitWavePerLeafUpTo = 16384, kWriteWavePerLeafUpTo = 7168;
 constexpr uint32_t kLeafTreeLds = 256;
 constexpr uint32_t kLeavesPerBlock = kBlock / 64u;
 struct ReshapeItem {  // walk stack of reshape_collector
