@@ -271,6 +271,42 @@ def test_guided_batches_of_one_workgroup(gpu_ctx, res):
     assert abs((gf * gs).mean() / (cf * cs).mean() - 1.0) < 0.25
 
 
+@pytest.mark.parametrize("name,kind,res", [("cornell-box", "path", (32, 32)), ("cornell-box", "lightpath", (32, 32)),
+                                            ("cornell-box-guided", "guided", (48, 32)), ("cornell-box-guided", "guided", (16, 16))])
+def test_census_variants_trace_the_same_paths(gpu_ctx, name, kind, res):
+    """ptgpu_set_census switches every walking kernel to its counting instantiation (k_extend<true, .>, k_occlude_*<true, .>,
+    k_walk_guided<true, .>): same films, same ray counts, and the counts they return are those of a walk — at least the
+    root per ray, never more than the whole tree per ray, the same again for the same paths."""
+    sc = pt.LoadedScene(name, resx=res[0], resy=res[1], max_depth=6, integrator=kind)
+    o = ob.OracleScene(sc)
+    gpu_ctx.load(sc)
+    spp = 3 if kind == "guided" else 4
+    f0, s0, st0 = gpu_ctx.render(sc.integrator, spp)
+    gpu_ctx.set_census(True)
+    try:
+        f1, s1, st1 = gpu_ctx.render(sc.integrator, spp)
+        census = gpu_ctx.census()
+    finally:
+        gpu_ctx.set_census(False)
+    assert s0 == s1 and all(st0[k] == st1[k] for k in ("samples", "extend_rays", "shadow_rays", "segments"))
+    if kind == "guided":   # float atomics of the record pass: the later waves differ in the last bits of the tree
+        assert abs((f1 * s1).mean() / (f0 * s0).mean() - 1.0) < 0.05
+    else:
+        np.testing.assert_allclose(f1, f0, rtol=1e-6, atol=1e-9)
+    info = o.info()
+    assert st1["extend_rays"] <= census["extend_nodes"] <= st1["extend_rays"] * info["n_nodes"]   # every ray looks at the root at least
+    assert 0 < census["extend_tris"] <= st1["extend_rays"] * info["n_tris"]
+    if st1["shadow_rays"]:
+        assert 0 < census["occlude_nodes"] <= st1["shadow_rays"] * info["n_nodes"] and census["occlude_tris"] <= st1["shadow_rays"] * info["n_tris"]
+    if kind != "guided":   # the same paths again: the same counts
+        gpu_ctx.set_census(True)
+        try:
+            gpu_ctx.render(sc.integrator, spp)
+            assert gpu_ctx.census() == census
+        finally:
+            gpu_ctx.set_census(False)
+
+
 def test_scene_without_emitters_renders_black(gpu_ctx):
     """No light to pick (Scene::choose_light returns None, scene.rs:257-268): every integrator returns a black film
     and traces the rays the oracle traces."""
