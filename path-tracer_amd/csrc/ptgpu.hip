@@ -170,6 +170,7 @@ struct ptgpu_ctx {
     GuidedPersist* guided_persist = nullptr;
     int bvh_builder = 2;               // ptgpu_set_bvh_builder: 0 host, 1 device, 2 device for scenes of kDeviceBuildFrom triangles and more
     bool bvh_built_on_device = false;  // how the resident scene's tree was built
+    bool has_passthrough = false;      // the resident scene has surfaces without a material (material_index < 0): walks may take more rounds than max_depth
     bool train_last_wave = true;       // ptgpu_set_final_training
     bool direct_splat = false;         // PTGPU_DIRECT_SPLAT, sampled at the start of a wave
     bool record_overlap = getenv("PTGPU_NO_OVERLAP") == nullptr;  // guided: record pass on the second stream (ptgpu_set_record_overlap)
@@ -461,6 +462,7 @@ int ptgpu_scene_create(ptgpu_ctx* c, const ptgpu_scene_desc* desc) {
     for (uint32_t i = 0; i < desc->n_meshes; i++)
         if (!desc->meshes[i].emissive) order.push_back(i);
 
+    bool any_passthrough = false;
     std::vector<BuildTri> build;
     std::vector<uint32_t> tri_mesh, tri_index;  // per input triangle id
     std::vector<MeshInfo> mesh_info(order.size());
@@ -471,6 +473,7 @@ int ptgpu_scene_create(ptgpu_ctx* c, const ptgpu_scene_desc* desc) {
         if (!mesh.points || !mesh.triangles) return fail(PTGPU_E_INVALID, "scene_create: mesh without points/triangles");
         if (mesh.material_index >= (int32_t)desc->n_materials) return fail(PTGPU_E_INVALID, "scene_create: material index out of range");
         mesh_info[m].material = mesh.material_index < 0 ? -1 : mesh.material_index;
+        if (mesh.material_index < 0 && mesh.n_triangles > 0) any_passthrough = true;
         mesh_info[m].has_normals = mesh.normals ? 1 : 0;
         if (m < n_emissive_meshes) emissions.push_back(to_dev(mesh.emission, 1));
         for (uint32_t t = 0; t < mesh.n_triangles; t++) {
@@ -584,6 +587,7 @@ int ptgpu_scene_create(ptgpu_ctx* c, const ptgpu_scene_desc* desc) {
     HIP_TRY(c->d_materials.upload(mats, c->stream));
     HIP_TRY(c->d_emissions.upload(emissions, c->stream));
     c->n_materials = (uint32_t)mats.size();
+    c->has_passthrough = any_passthrough;
     c->n_emissions = (uint32_t)emissions.size();
     HIP_TRY(c->d_emissive.upload(emissive_leaf, c->stream));
     SceneDev& s = c->scene;
@@ -888,14 +892,17 @@ uint32_t pick_capacity(const ptgpu_ctx* c, uint64_t total_paths) {
 }
 
 // One batch of camera or light paths through all bounces. Returns the number of rounds run.
+// `deferred_at` >= 0: the scene has no pass-through surface, so the walk ends after exactly max_depth rounds and the host
+// need not look at the queue: the batch uses the counters from index deferred_at on (cleared by the caller), nothing is
+// read back here and the GPU goes from this batch straight into the next (flush_deferred_counters reads them all).
 int run_batch_path_like(ptgpu_ctx* c, bool light, const RenderParams& rp, uint32_t n_paths, uint64_t first_sample, uint64_t sample_step,
-                        ptgpu_stats* stats) {
+                        ptgpu_stats* stats, int deferred_at = -1) {
     const uint32_t npix = c->camera.resx * c->camera.resy;
-    HIP_TRY(hipMemsetAsync(c->d_counters.p, 0, c->d_counters.n * sizeof(RoundCounters), c->stream));
+    if (deferred_at < 0) HIP_TRY(hipMemsetAsync(c->d_counters.p, 0, c->d_counters.n * sizeof(RoundCounters), c->stream));
     PathCols A = c->set_a.view(c->capacity), B = c->set_b.view(c->capacity);
     HitCols H{c->d_hit_tb.p, c->d_hit_prim.p};
     ShadowCols S = shadow_view(c);
-    RoundCounters* cnt = c->d_counters.p;
+    RoundCounters* cnt = c->d_counters.p + (deferred_at < 0 ? 0 : deferred_at);
     const int grid = grid_for(c, n_paths);
     if (light) {
         {
@@ -939,6 +946,10 @@ int run_batch_path_like(ptgpu_ctx* c, bool light, const RenderParams& rp, uint32
         HIP_TRY(hipGetLastError());
         std::swap(A, B);
         round++;
+        if (deferred_at >= 0) {
+            if (round >= sure_rounds) return PTGPU_OK;
+            continue;
+        }
         if (round >= sure_rounds || (round & 15) == 0) {  // the host looks at the queue length rarely: every look drains the stream
             // all counters so far in one copy: the look that finds the queue empty is also the batch's statistics
             HIP_TRY(hipMemcpyAsync(c->h_counters.data(), cnt, (size_t)(round + 1) * sizeof(RoundCounters), hipMemcpyDeviceToHost, c->stream));
@@ -953,6 +964,25 @@ int run_batch_path_like(ptgpu_ctx* c, bool light, const RenderParams& rp, uint32
             stats->segments += c->h_counters[r].n_segments;
         }
         stats->samples += n_paths;
+    }
+    return PTGPU_OK;
+}
+
+// Counters of `n_batches` deferred batches of `per_batch` entries each: one copy, one wait, the statistics of all of them.
+int flush_deferred_counters(ptgpu_ctx* c, uint32_t n_batches, uint32_t per_batch, const std::vector<uint32_t>& batch_paths, ptgpu_stats* stats) {
+    if (n_batches == 0) return PTGPU_OK;
+    HIP_TRY(hipMemcpyAsync(c->h_counters.data(), c->d_counters.p, (size_t)n_batches * per_batch * sizeof(RoundCounters), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (uint32_t b = 0; b < n_batches; b++) {
+        const RoundCounters* h = c->h_counters.data() + (size_t)b * per_batch;
+        if (h[per_batch - 1].n_active != 0) return fail(PTGPU_E_STATE, "render: paths left after max_depth rounds in a scene without pass-through surfaces");
+        if (!stats) continue;
+        for (uint32_t r = 0; r < per_batch; r++) {
+            stats->extend_rays += h[r].n_active;
+            stats->shadow_rays += h[r].n_shadow;
+            stats->segments += h[r].n_segments;
+        }
+        stats->samples += batch_paths[b];
     }
     return PTGPU_OK;
 }
@@ -979,11 +1009,30 @@ int render_path_like(ptgpu_ctx* c, const ptgpu_integrator_desc* integ, uint32_t 
     rp.film_copies = c->film_copies;
     rp.n_pixels = (uint32_t)npix;
     const uint64_t passes_per_batch = c->capacity / npix;
+    // Without pass-through surfaces every batch takes exactly max_depth rounds: batches follow one another on the stream
+    // without a look from the host in between (each look drained the GPU: ~0.2 ms per batch, 4 % of veach-mis), each with
+    // counters of its own; the host reads a group of them in one copy.
+    static const bool sync_batches = getenv("PTGPU_SYNC_BATCHES") != nullptr;  // A/B: the host looks after every batch
+    const bool deferred = !c->has_passthrough && rp.max_depth + 1u <= 1024u && !sync_batches;
+    const uint32_t per_batch = rp.max_depth + 1u, group = deferred ? (uint32_t)((c->d_counters.n) / per_batch) : 0u;
+    std::vector<uint32_t> batch_paths;
     for (uint64_t done = 0; done < my_samples; done += passes_per_batch) {
         const uint64_t passes = std::min(passes_per_batch, my_samples - done);
         const uint64_t first = shard_index + done * shard_count;
-        rc = run_batch_path_like(c, light, rp, (uint32_t)(passes * npix), first, shard_count, stats);
-        if (rc != PTGPU_OK) return rc;
+        if (deferred) {
+            if (batch_paths.empty()) HIP_TRY(hipMemsetAsync(c->d_counters.p, 0, c->d_counters.n * sizeof(RoundCounters), c->stream));
+            rc = run_batch_path_like(c, light, rp, (uint32_t)(passes * npix), first, shard_count, stats, (int)(batch_paths.size() * per_batch));
+            if (rc != PTGPU_OK) return rc;
+            batch_paths.push_back((uint32_t)(passes * npix));
+            if (batch_paths.size() == group || done + passes_per_batch >= my_samples) {
+                rc = flush_deferred_counters(c, (uint32_t)batch_paths.size(), per_batch, batch_paths, stats);
+                if (rc != PTGPU_OK) return rc;
+                batch_paths.clear();
+            }
+        } else {
+            rc = run_batch_path_like(c, light, rp, (uint32_t)(passes * npix), first, shard_count, stats);
+            if (rc != PTGPU_OK) return rc;
+        }
     }
     return PTGPU_OK;
 }
