@@ -228,6 +228,23 @@ def test_small_batches_equal_one_big_batch(gpu_ctx):
     assert np.allclose(a, b, rtol=1e-9, atol=1e-12)
 
 
+def test_more_batches_than_one_group_of_counters(gpu_ctx):
+    """Scenes without pass-through surfaces: batches run back to back, each on counters of its own, and the host reads a
+    whole group of them in one copy (65 538 counters / (max_depth + 1) batches). 5 000 one-pass batches of an 8 x 8 image
+    at depth 16 take two groups; film and ray counts must be those of the same render in one batch."""
+    sc = pt.LoadedScene("cornell-box", resx=8, resy=8, max_depth=16)
+    gpu_ctx.load(sc)
+    a, sa, sta = gpu_ctx.render(sc.integrator, 5000)
+    gpu_ctx.set_batch_paths(64)
+    try:
+        b, sb, stb = gpu_ctx.render(sc.integrator, 5000)
+    finally:
+        gpu_ctx.set_batch_paths(0)
+    assert sa == sb and all(sta[k] == stb[k] for k in ("samples", "extend_rays", "shadow_rays", "segments"))
+    assert sta["samples"] == 64 * 5000
+    assert np.allclose(a, b, rtol=1e-9, atol=1e-12)
+
+
 @pytest.mark.parametrize("kind", [pt.INTEGRATOR_PATH, pt.INTEGRATOR_LIGHTPATH])
 def test_ragged_image_sizes_match_oracle(gpu_ctx, kind):
     """Width and height that are not multiples of the 16 x 16 tile (integrator/mod.rs:34-46 clips the last tiles)."""
