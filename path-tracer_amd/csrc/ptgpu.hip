@@ -52,7 +52,12 @@ struct DevBuf {
         n = count;
         cap = count;
         if (count == 0) return hipSuccess;
-        return hipMalloc((void**)&p, count * sizeof(T));
+        const hipError_t e = hipMalloc((void**)&p, count * sizeof(T));
+        if (e != hipSuccess) {  // nothing is held: a later reserve() of less must not take the failed size for capacity
+            p = nullptr;
+            n = cap = 0;
+        }
+        return e;
     }
     hipError_t upload(const std::vector<T>& v, hipStream_t s) {
         hipError_t e = alloc(v.size());
@@ -238,6 +243,20 @@ int ensure_workspace(ptgpu_ctx* c, uint32_t cap) {
     c->h_top_counters.assign(kMaxRounds + 2, 0u);
     c->capacity = cap;
     return PTGPU_OK;
+}
+// ensure_workspace for `cap` paths or, where the device has not that much memory left, for the largest whole multiple
+// of `unit` paths (one sample pass of the image) that it has, halving until it fits.
+int ensure_workspace_or_smaller(ptgpu_ctx* c, uint64_t cap, uint64_t unit) {
+    for (;;) {
+        const int rc = ensure_workspace(c, (uint32_t)cap);
+        size_t free_b = 0, total_b = 0;
+        // (a workspace that leaves less than 2 GB free is too large as well: tables and the film come after it)
+        if (rc == PTGPU_OK && (cap <= unit || hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b >= ((size_t)2 << 30))) return rc;
+        const bool out_of_memory = rc == PTGPU_OK || hipGetLastError() == hipErrorOutOfMemory;
+        c->capacity = 0;  // whatever was allocated is not a consistent workspace
+        if (!out_of_memory || cap <= unit) return rc;
+        cap = std::max(unit, (cap / 2 / unit) * unit);
+    }
 }
 ShadowCols shadow_view(ptgpu_ctx* c) {
     ShadowCols s;
@@ -997,7 +1016,7 @@ int render_path_like(ptgpu_ctx* c, const ptgpu_integrator_desc* integ, uint32_t 
     const uint64_t my_samples = spp > shard_index ? ((uint64_t)spp - shard_index + shard_count - 1) / shard_count : 0;
     HIP_TRY(hipMemsetAsync(c->d_film.p, 0, c->d_film.n * sizeof(double), c->stream));
     if (my_samples == 0 || integ->max_depth == 0) return PTGPU_OK;
-    int rc = ensure_workspace(c, pick_capacity(c, my_samples * npix));
+    int rc = ensure_workspace_or_smaller(c, pick_capacity(c, my_samples * npix), npix);
     if (rc != PTGPU_OK) return rc;
     rc = upload_lambda_table(c, golden_iterates(spp));
     if (rc != PTGPU_OK) return rc;
