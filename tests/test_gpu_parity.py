@@ -245,6 +245,41 @@ def test_more_batches_than_one_group_of_counters(gpu_ctx):
     assert np.allclose(a, b, rtol=1e-9, atol=1e-12)
 
 
+def test_batches_shrink_to_the_memory_the_device_has_left(gpu_ctx):
+    """Batches are sized for a whole MI355X (tens of GB of per-path buffers). With a bystander holding all but 14 GB of
+    the device, the same renders go through in smaller batches: same sample counts, same image (path: the very same
+    paths; guided: the same up to the statistics of its float atomics)."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    guided = pt.LoadedScene("cornell-box-guided", resx=256, resy=256)          # 64 spp: 4.2 M paths, ~22 GB of batch buffers
+    path = pt.LoadedScene("veach-mis", resx=640, resy=360)                     # 256 spp: 59 M paths, ~22 GB
+    gpu_ctx.load(guided)
+    g0, gs0, gst0 = gpu_ctx.render(guided.integrator, 64)
+    gpu_ctx.load(path)
+    p0, ps0, pst0 = gpu_ctx.render(path.integrator, 256)
+    gpu_ctx.set_batch_paths(1 << 16)   # gives the large buffers back (the workspace is re-made per capacity)
+    gpu_ctx.render(path.integrator, 1)
+    gpu_ctx.set_batch_paths(0)
+    free, total, hog = ctypes.c_size_t(0), ctypes.c_size_t(0), ctypes.c_void_p(None)
+    assert hip.hipMemGetInfo(ctypes.byref(free), ctypes.byref(total)) == 0
+    assert hip.hipMalloc(ctypes.byref(hog), ctypes.c_size_t(max(1, free.value - 14 * 2**30))) == 0   # the bystander
+    try:
+        p1, ps1, pst1 = gpu_ctx.render(path.integrator, 256)
+        other = pt.Context(0)   # (gpu_ctx keeps the guided integrator's buffers of the first render: a context of its own starts from nothing)
+        try:
+            other.load(guided)
+            g1, gs1, gst1 = other.render(guided.integrator, 64)
+        finally:
+            other.close()
+    finally:
+        assert hip.hipFree(hog) == 0
+    assert pst1["samples"] == pst0["samples"] == 640 * 360 * 256 and pst1["extend_rays"] == pst0["extend_rays"]
+    assert pst1["kernel_launches"] > pst0["kernel_launches"] and gst1["kernel_launches"] > gst0["kernel_launches"]   # more, smaller batches
+    assert np.allclose(p1, p0, rtol=1e-9, atol=1e-12)
+    assert gst1["samples"] == gst0["samples"] == 256 * 256 * 64
+    assert abs((g1 * gs1).mean() / (g0 * gs0).mean() - 1.0) < 0.03
+
+
 @pytest.mark.parametrize("kind", [pt.INTEGRATOR_PATH, pt.INTEGRATOR_LIGHTPATH])
 def test_ragged_image_sizes_match_oracle(gpu_ctx, kind):
     """Width and height that are not multiples of the 16 x 16 tile (integrator/mod.rs:34-46 clips the last tiles)."""
