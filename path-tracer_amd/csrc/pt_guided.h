@@ -597,9 +597,7 @@ __global__ __launch_bounds__(kBlock) void k_raygen_guided(SceneDev sc, CameraDev
             const uint32_t lam = index_in_tile(pixel, cam.resx) + (pass == 0 ? 0u : 256u);
             st.o_pdf[slot] = make_float4(o.x, o.y, o.z, u2f(slot));  // w: path id (vertex-store column); the previous vertex' point
                                                                      // and pdf, which `path` keeps here, are read back from its line
-            st.d_flags[slot] = make_float4(d.x, d.y, d.z, u2f(0u));
-            st.beta0[slot] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
-            st.beta1[slot] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+            st.d_flags[slot] = make_float4(d.x, d.y, d.z, u2f(FLAG_FRESH));  // throughput 1: k_shade_guided knows
             st.rng_px[slot] = make_uint4((uint32_t)rng.state, (uint32_t)(rng.state >> 32), pixel, lam);  // w: lambda index | nverts << 16
         }
     }
@@ -697,6 +695,8 @@ __global__ __launch_bounds__(kBlock, KINDS != 7 ? PT_GUIDED_DIFFUSE_WAVES : PT_S
             o = mk3(o4.x, o4.y, o4.z);
             d = mk3(d4.x, d4.y, d4.z);
             flags = f2u(d4.w);
+            const bool fresh = (flags & FLAG_FRESH) != 0u;  // straight out of k_raygen_guided: throughput 1, not stored
+            flags &= ~FLAG_FRESH;
             rp4 = in.rng_px[i];
             pid = f2u(o4.w);
             nverts = rp4.w >> 16;
@@ -714,7 +714,7 @@ __global__ __launch_bounds__(kBlock, KINDS != 7 ? PT_GUIDED_DIFFUSE_WAVES : PT_S
                 PT_TICK(12);
             } else {
                 const float4 tb = hit.tb[i];
-                beta = load_spec(in.beta0, in.beta1, i);
+                beta = fresh ? spec_splat(1.0f) : load_spec(in.beta0, in.beta1, i);
                 const uint32_t row = rp4.w & 0xffffu;  // wavelength-table row of this path
                 const Surface sf = make_surface(sc, prim, tb.y, tb.z, tb.w);
                 const int material = tag_material(prim_tag.y);

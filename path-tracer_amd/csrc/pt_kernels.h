@@ -300,13 +300,8 @@ __global__ __launch_bounds__(kBlock) void k_raygen_camera(SceneDev sc, CameraDev
         V3 o, d;
         camera_sample_we(cam, ix, iy, u0, u1, o, d);
         st.o_pdf[g] = make_float4(o.x, o.y, o.z, 0.0f);
-        st.d_flags[g] = make_float4(d.x, d.y, d.z, u2f(0u));
-        st.beta0[g] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
-        st.beta1[g] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
-        st.L0[g] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        st.L1[g] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        st.d_flags[g] = make_float4(d.x, d.y, d.z, u2f(FLAG_FRESH));  // beta = 1, L = 0, no previous vertex, path id = g: k_shade_path knows
         st.rng_px[g] = make_uint4((uint32_t)rng.state, (uint32_t)(rng.state >> 32), pixel, (uint32_t)si);
-        st.prev_p[g] = make_float4(0.0f, 0.0f, 0.0f, u2f(g));
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) cnt[0].n_active = n_paths;
 }
@@ -417,18 +412,25 @@ __global__ __launch_bounds__(kBlock, KINDS != 7 ? PT_PATH_DIFFUSE_WAVES : PT_SHA
             d = mk3(d4.x, d4.y, d4.z);
             prev_pdf = o4.w;
             flags = f2u(d4.w);
+            const bool fresh = (flags & FLAG_FRESH) != 0u;  // straight out of k_raygen_camera: 80 bytes of state that need not be read
+            flags &= ~FLAG_FRESH;
             rp4 = in.rng_px[i];
-            L = load_spec(in.L0, in.L1, i);
+            if (!fresh) L = load_spec(in.L0, in.L1, i);
             const uint2 prim_tag = hit.prim[i];
             const uint32_t prim = prim_tag.x;
             if (prim == kNoHit) {
                 do_film = true;  // eval_envmap == ZERO without an envmap (scene.rs:301-306)
             } else {
                 const float4 tb = hit.tb[i];
-                const float4 pp = in.prev_p[i];
-                prev_p = mk3(pp.x, pp.y, pp.z);
-                pid = f2u(pp.w);
-                beta = load_spec(in.beta0, in.beta1, i);
+                if (fresh) {
+                    pid = i;
+                    beta = spec_splat(1.0f);
+                } else {
+                    const float4 pp = in.prev_p[i];
+                    prev_p = mk3(pp.x, pp.y, pp.z);
+                    pid = f2u(pp.w);
+                    beta = load_spec(in.beta0, in.beta1, i);
+                }
                 const Surface sf = make_surface(sc, prim, tb.y, tb.z, tb.w);
                 const int material = tag_material(prim_tag.y);
                 uint32_t depth = flags & FLAG_DEPTH_MASK;

@@ -26,6 +26,9 @@ constexpr uint32_t kMaxPassThrough = 256;
 // path is queued — predicted-specular survivors fill the state set from the top, the others from the bottom
 // (slot_of_index) — so that the lanes of a wave run the same material code; no result depends on it.
 constexpr uint32_t FLAG_INSIDE = 1u << 30;
+// A path straight out of ray generation: throughput 1, no radiance yet, no previous vertex, path id = slot. Ray generation
+// writes origin, direction and sampler state only; the first shade pass fills in the rest instead of loading it.
+constexpr uint32_t FLAG_FRESH = 1u << 31;
 PT_HD bool passthrough_step(uint32_t& flags) {
     const uint32_t n = ((flags & FLAG_PASS_MASK) >> FLAG_PASS_SHIFT) + 1;
     flags = (flags & ~FLAG_PASS_MASK) | (n << FLAG_PASS_SHIFT);
