@@ -247,6 +247,7 @@ int ensure_workspace(ptgpu_ctx* c, uint32_t cap) {
 // ensure_workspace for `cap` paths or, where the device has not that much memory left, for the largest whole multiple
 // of `unit` paths (one sample pass of the image) that it has, halving until it fits.
 int ensure_workspace_or_smaller(ptgpu_ctx* c, uint64_t cap, uint64_t unit) {
+    if (c->capacity == cap && c->set_a.cols.p) return PTGPU_OK;  // the workspace of the previous render
     for (;;) {
         const int rc = ensure_workspace(c, (uint32_t)cap);
         size_t free_b = 0, total_b = 0;
