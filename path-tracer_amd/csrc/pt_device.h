@@ -638,6 +638,139 @@ PT_D Hit bvh_intersect(const SceneDev& sc, V3 o, V3 d, float ray_end_t, uint32_t
     if (sc.lds_nodes) return bvh_intersect_binary<COUNT, ANY_HIT, true>(sc, o, d, ray_end_t, n_nodes_visited, n_tris_tested);
     return bvh_intersect_binary<COUNT, ANY_HIT, false>(sc, o, d, ray_end_t, n_nodes_visited, n_tris_tested);
 }
+// ------------------------------------------------------------------ the four-wide walk over a STREAM of rays
+// bvh_intersect serves one ray per lane and returns when the slowest lane of the wave is done. In a large scene the
+// rays of a wave (unrelated bounce rays after compaction) differ widely in length: veach-mis runs its walkers with
+// 0.28 of the lanes active. Here a wave owns a sequence of rays (its 64-ray pieces of the queue, a grid stride apart),
+// and a lane whose ray is finished hands in its result and takes the wave's next ray while the others walk on. Per ray
+// nothing changes — the same nodes in the same order, the same triangle tests, the same culls as bvh_intersect_wide —,
+// only which lane serves which ray does. Lanes are refilled between two rounds of the while-while loop, once
+// kRefillAt of them are free (a refill runs the ray set-up, six IEEE divisions, for the whole wave) or none has work.
+//   fetch(j, o, d) : ray j of the queue; emit(j, hit) : its result.
+#ifndef PT_REFILL_AT
+#define PT_REFILL_AT 16
+#endif
+constexpr uint32_t kRefillAt = PT_REFILL_AT;
+template <bool COUNT, bool STAGED, class Fetch, class Emit>
+PT_D void bvh_stream_wide(const SceneDev& sc, uint32_t n, Fetch fetch, Emit emit, uint32_t* n_nodes_visited, uint32_t* n_tris_tested) {
+    extern __shared__ uint32_t sm_bvh_stack[];
+    uint32_t* stack = sm_bvh_stack + threadIdx.x;
+    uint32_t* pend = sm_bvh_stack + sc.wide_stack * kBlock + threadIdx.x;
+    const float4* lds_nodes = reinterpret_cast<const float4*>(sm_bvh_stack + (sc.wide_stack + kLeafQueue) * kBlock);
+    const float ray_end_t = f_inf();
+    const float slack = 1.0f + 2.0f * gamma_n(3.0f);
+    const float kCullSlack = 1.0f + 0x1p-19f;
+    const uint32_t lane = __lane_id();
+    // this wave's rays: s = 0, 1, ... -> queue index base + (s / 64) * stride + s % 64
+    const uint32_t base = blockIdx.x * kBlock + (threadIdx.x & ~63u), stride = gridDim.x * kBlock;
+    const uint32_t total = base < n ? ((n - base + stride - 1u) / stride) * 64u : 0u;
+    uint32_t next = 0;  // wave-uniform
+    V3 o = mk3(0.0f, 0.0f, 0.0f), inv = o;
+    RayShear shear{0, 0.0f, 0.0f, 0.0f};
+    uint32_t octant = 0, sp = 0, cur = 0, j = 0;
+    bool have_ray = false, have = false;
+    Hit best;
+    best.prim = kNoHit;
+    best.tag = 0;
+    best.th.t = ray_end_t;
+    best.th.b0 = best.th.b1 = best.th.b2 = 0.0f;
+    for (;;) {
+        if (have_ray && !have) {  // this lane's ray is done
+            if (!(best.th.t != ray_end_t)) best.prim = kNoHit;  // bvh.rs:137
+            if (best.prim != kNoHit) best.tag = f2u(sc.tri_v[3 * best.prim + 2].w);
+            emit(j, best);
+            have_ray = false;
+        }
+        const unsigned long long free_mask = __ballot(!have_ray);
+        const uint32_t n_free = (uint32_t)__popcll(free_mask);
+        if (next < total && (n_free >= kRefillAt || n_free == 64u)) {
+            if (!have_ray) {
+                const uint32_t s = next + (uint32_t)__popcll(free_mask & ((1ull << lane) - 1ull));
+                const uint32_t jj = base + (s >> 6) * stride + (s & 63u);
+                if (s < total && jj < n) {
+                    V3 d;
+                    fetch(jj, o, d);
+                    j = jj;
+                    inv = splat(1.0f) / d;
+                    octant = (inv.x < 0.0f ? 1u : 0u) | (inv.y < 0.0f ? 2u : 0u) | (inv.z < 0.0f ? 4u : 0u);
+                    shear = ray_shear(d);
+                    best.prim = kNoHit;
+                    best.th.t = ray_end_t;
+                    best.th.b0 = best.th.b1 = best.th.b2 = 0.0f;
+                    sp = 0;
+                    cur = 0;
+                    have_ray = have = true;
+                }
+            }
+            next += n_free;
+        } else if (n_free == 64u)
+            break;
+        const bool nx = (octant & 1u) != 0u, ny = (octant & 2u) != 0u, nz = (octant & 4u) != 0u;
+        const V3 sinv = mk3(slack * inv.x, slack * inv.y, slack * inv.z);
+        uint32_t n_pend = 0;
+        while (have && n_pend < kLeafQueue) {
+            if (cur & 0x80000000u) {
+                pend[n_pend * kBlock] = cur;
+                n_pend++;
+            } else {
+                float4 lox, loy, loz, hix, hiy, hiz, refs_f, meta_f;
+                if (STAGED) {
+                    const float4* wn = lds_nodes + 8 * cur;
+                    lox = wn[0], loy = wn[1], loz = wn[2], hix = wn[3], hiy = wn[4], hiz = wn[5], refs_f = wn[6], meta_f = wn[7];
+                } else {
+                    const float4* wn = sc.wnodes + 8 * (size_t)cur;
+                    lox = wn[0], loy = wn[1], loz = wn[2], hix = wn[3], hiy = wn[4], hiz = wn[5], refs_f = wn[6], meta_f = wn[7];
+                }
+                const uint32_t refs[4] = {f2u(refs_f.x), f2u(refs_f.y), f2u(refs_f.z), f2u(refs_f.w)};
+                const uint32_t table = octant < 4u ? f2u(meta_f.x) : f2u(meta_f.y);
+                const uint32_t perm = (table >> (8u * (octant & 3u))) & 0xffu, n_children = f2u(meta_f.z);
+                const float nearx[4] = {nx ? hix.x : lox.x, nx ? hix.y : lox.y, nx ? hix.z : lox.z, nx ? hix.w : lox.w};
+                const float farx[4] = {nx ? lox.x : hix.x, nx ? lox.y : hix.y, nx ? lox.z : hix.z, nx ? lox.w : hix.w};
+                const float neary[4] = {ny ? hiy.x : loy.x, ny ? hiy.y : loy.y, ny ? hiy.z : loy.z, ny ? hiy.w : loy.w};
+                const float fary[4] = {ny ? loy.x : hiy.x, ny ? loy.y : hiy.y, ny ? loy.z : hiy.z, ny ? loy.w : hiy.w};
+                const float nearz[4] = {nz ? hiz.x : loz.x, nz ? hiz.y : loz.y, nz ? hiz.z : loz.z, nz ? hiz.w : loz.w};
+                const float farz[4] = {nz ? loz.x : hiz.x, nz ? loz.y : hiz.y, nz ? loz.z : hiz.z, nz ? loz.w : hiz.w};
+                uint32_t hit_mask = 0;
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    float tmin = 0.0f, tmax = ray_end_t, t_dom;
+                    float t0 = inv.x * (nearx[c] - o.x);
+                    float t1 = sinv.x * (farx[c] - o.x);
+                    t_dom = t0;
+                    tmin = fmaxf(tmin, t0);
+                    tmax = fminf(tmax, t1);
+                    t0 = inv.y * (neary[c] - o.y);
+                    t1 = sinv.y * (fary[c] - o.y);
+                    t_dom = shear.kz == 1 ? t0 : t_dom;
+                    tmin = fmaxf(tmin, t0);
+                    tmax = fminf(tmax, t1);
+                    t0 = inv.z * (nearz[c] - o.z);
+                    t1 = sinv.z * (farz[c] - o.z);
+                    t_dom = shear.kz == 2 ? t0 : t_dom;
+                    tmin = fmaxf(tmin, t0);
+                    tmax = fminf(tmax, t1);
+                    if ((uint32_t)c < n_children && (0.0f <= tmin) && (tmin <= tmax) && (t_dom <= best.th.t * kCullSlack)) hit_mask |= 1u << c;
+                }
+                if (COUNT) (*n_nodes_visited) += n_children;
+#pragma unroll
+                for (int k = 3; k >= 0; k--) {  // last to visit first, so that the first is on top
+                    const uint32_t c = (perm >> (2 * k)) & 3u;
+                    if ((uint32_t)k < n_children && ((hit_mask >> c) & 1u) && sp < sc.wide_stack) {
+                        stack[sp * kBlock] = c == 0u ? refs[0] : (c == 1u ? refs[1] : (c == 2u ? refs[2] : refs[3]));
+                        sp++;
+                    }
+                }
+            }
+            if (sp > 0) cur = stack[(--sp) * kBlock];
+            else have = false;
+        }
+        for (uint32_t q = 0; q < n_pend; q++) {
+            const uint32_t ref = pend[q * kBlock];
+            (void)bvh_test_leaf<COUNT, false>(sc, o, shear, ray_end_t, ref & 0xffffffu, ((ref >> 24) & 0x7fu) + 1u, best, n_tris_tested);
+        }
+    }
+}
+
 // Scene::occluded (scene.rs:229-235): unnormalised segment, t_max 0.9999; only the boolean leaves this function.
 template <bool COUNT = false, bool WIDE = false>
 PT_D bool scene_occluded(const SceneDev& sc, V3 from, V3 to, uint32_t* n_nodes = nullptr, uint32_t* n_tris = nullptr) {

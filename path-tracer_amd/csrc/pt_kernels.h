@@ -329,6 +329,35 @@ __global__ __launch_bounds__(kBlock, WIDE ? PT_WIDE_WAVES : 8) void k_extend(Sce
     if (CENSUS) census_add(census, 0, cn, ct);
 }
 
+// The same for the four-wide walk over the queue as a stream (bvh_stream_wide): lanes take a new ray as they finish.
+#ifndef PT_STREAM_WAVES
+#define PT_STREAM_WAVES 6
+#endif
+template <bool CENSUS>
+__global__ __launch_bounds__(kBlock, PT_STREAM_WAVES) void k_extend_stream(SceneDev sc, PathCols st, HitCols hit, const RoundCounters* cnt, unsigned long long* census, const uint32_t* top,
+                                                                          uint32_t capacity) {
+    const uint32_t n_bottom = cnt->n_active;
+    const uint32_t n = n_bottom + (top ? *top : 0u);
+    if (blockIdx.x * blockDim.x >= n) return;
+    bvh_stage_nodes<true>(sc);
+    uint32_t cn = 0, ct = 0;
+    const auto fetch = [&](uint32_t j, V3& o, V3& d) {
+        const uint32_t i = slot_of_index(j, n_bottom, capacity);
+        float4 a = st.o_pdf[i], b = st.d_flags[i];
+        asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(b.x), "+v"(b.y), "+v"(b.z));
+        o = mk3(a.x, a.y, a.z);
+        d = mk3(b.x, b.y, b.z);
+    };
+    const auto emit = [&](uint32_t j, const Hit& h) {
+        const uint32_t i = slot_of_index(j, n_bottom, capacity);
+        hit.tb[i] = make_float4(h.th.t, h.th.b0, h.th.b1, h.th.b2);
+        hit.prim[i] = make_uint2(h.prim, h.tag);
+    };
+    if (sc.lds_wnodes) bvh_stream_wide<CENSUS, true>(sc, n, fetch, emit, &cn, &ct);
+    else bvh_stream_wide<CENSUS, false>(sc, n, fetch, emit, &cn, &ct);
+    if (CENSUS) census_add(census, 0, cn, ct);
+}
+
 // Parity hook: caller-supplied rays (ox,oy,oz,dx,dy,dz,tmax) -> ptgpu_hit-shaped records + traversal counts.
 struct HitOut {
     uint32_t mesh_index, triangle_index, leaf_index, hit;

@@ -877,6 +877,15 @@ int ptgpu_set_batch_paths(ptgpu_ctx* c, uint32_t n_paths) {
 namespace {
 
 void launch_extend(ptgpu_ctx* c, int grid, const PathCols& A, const HitCols& H, const RoundCounters* cnt, const uint32_t* top = nullptr) {
+    // The four-wide closest-hit walk takes its queue as a stream (lanes refilled as their rays finish: veach-mis extend
+    // 31.2 -> 29.0 ms per 128 spp); the binary walk of small scenes does not (most rays finish inside one round of the
+    // while-while loop: nothing to refill, Cornell extend +13 %). PTGPU_STREAM_WALK=0: one ray per lane and trip everywhere.
+    static const bool stream_walk = getenv("PTGPU_STREAM_WALK") ? atoi(getenv("PTGPU_STREAM_WALK")) != 0 : true;
+    if (stream_walk && c->wide) {
+        if (c->census_on) PT_LAUNCH_WALK(c, k_extend_stream<true>, grid, c->scene, A, H, cnt, c->d_census.p, top, c->capacity);
+        else PT_LAUNCH_WALK(c, k_extend_stream<false>, grid, c->scene, A, H, cnt, c->d_census.p, top, c->capacity);
+        return;
+    }
     if (c->census_on) PT_LAUNCH_WALK(c, PT_WALKER(c, k_extend, true), grid, c->scene, A, H, cnt, c->d_census.p, top, c->capacity);
     else PT_LAUNCH_WALK(c, PT_WALKER(c, k_extend, false), grid, c->scene, A, H, cnt, c->d_census.p, top, c->capacity);
 }
