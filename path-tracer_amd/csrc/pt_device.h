@@ -651,13 +651,12 @@ PT_D Hit bvh_intersect(const SceneDev& sc, V3 o, V3 d, float ray_end_t, uint32_t
 #define PT_REFILL_AT 16
 #endif
 constexpr uint32_t kRefillAt = PT_REFILL_AT;
-template <bool COUNT, bool STAGED, class Fetch, class Emit>
-PT_D void bvh_stream_wide(const SceneDev& sc, uint32_t n, Fetch fetch, Emit emit, uint32_t* n_nodes_visited, uint32_t* n_tris_tested) {
+template <bool COUNT, bool ANY_HIT, bool STAGED, class Fetch, class Emit>
+PT_D void bvh_stream_wide(const SceneDev& sc, uint32_t n, const float ray_end_t, Fetch fetch, Emit emit, uint32_t* n_nodes_visited, uint32_t* n_tris_tested) {
     extern __shared__ uint32_t sm_bvh_stack[];
     uint32_t* stack = sm_bvh_stack + threadIdx.x;
     uint32_t* pend = sm_bvh_stack + sc.wide_stack * kBlock + threadIdx.x;
     const float4* lds_nodes = reinterpret_cast<const float4*>(sm_bvh_stack + (sc.wide_stack + kLeafQueue) * kBlock);
-    const float ray_end_t = f_inf();
     const float slack = 1.0f + 2.0f * gamma_n(3.0f);
     const float kCullSlack = 1.0f + 0x1p-19f;
     const uint32_t lane = __lane_id();
@@ -677,7 +676,7 @@ PT_D void bvh_stream_wide(const SceneDev& sc, uint32_t n, Fetch fetch, Emit emit
     for (;;) {
         if (have_ray && !have) {  // this lane's ray is done
             if (!(best.th.t != ray_end_t)) best.prim = kNoHit;  // bvh.rs:137
-            if (best.prim != kNoHit) best.tag = f2u(sc.tri_v[3 * best.prim + 2].w);
+            if (!ANY_HIT && best.prim != kNoHit) best.tag = f2u(sc.tri_v[3 * best.prim + 2].w);
             emit(j, best);
             have_ray = false;
         }
@@ -764,10 +763,12 @@ PT_D void bvh_stream_wide(const SceneDev& sc, uint32_t n, Fetch fetch, Emit emit
             if (sp > 0) cur = stack[(--sp) * kBlock];
             else have = false;
         }
-        for (uint32_t q = 0; q < n_pend; q++) {
+        bool decided = false;  // ANY_HIT: the occlusion query is answered (see bvh_intersect), the rest of the walk is dropped
+        for (uint32_t q = 0; q < n_pend && !decided; q++) {
             const uint32_t ref = pend[q * kBlock];
-            (void)bvh_test_leaf<COUNT, false>(sc, o, shear, ray_end_t, ref & 0xffffffu, ((ref >> 24) & 0x7fu) + 1u, best, n_tris_tested);
+            decided = bvh_test_leaf<COUNT, ANY_HIT>(sc, o, shear, ray_end_t, ref & 0xffffffu, ((ref >> 24) & 0x7fu) + 1u, best, n_tris_tested);
         }
+        if (ANY_HIT && decided) have = false;
     }
 }
 

@@ -906,6 +906,29 @@ __global__ __launch_bounds__(kBlock) void k_occlude_guided(SceneDev sc, GuidedPa
     if (CENSUS) census_add(census, 2, cn, ct);
 }
 
+// The same over the shadow queue as a stream (bvh_stream_wide), for the four-wide walk of large scenes.
+template <bool CENSUS>
+__global__ __launch_bounds__(kBlock, PT_STREAM_WAVES) void k_occlude_guided_stream(SceneDev sc, GuidedParams gp, ShadowCols sh, const RoundCounters* cnt, unsigned long long* census) {
+    const uint32_t n = cnt->n_shadow;
+    if (blockIdx.x * blockDim.x >= n) return;
+    bvh_stage_nodes<true>(sc);
+    uint32_t cn = 0, ct = 0;
+    const auto fetch = [&](uint32_t j, V3& o, V3& d) {
+        const float4 a = sh.q0[j], q = sh.q1[j];
+        o = mk3(a.x, a.y, a.z);
+        d = mk3(q.x, q.y, q.z) - o;  // Scene::occluded: unnormalised segment, t_max 0.9999
+    };
+    const auto emit = [&](uint32_t j, const Hit& h) {
+        if (h.prim == kNoHit) return;
+        float4* v = gp.vtx.at(f2u(sh.q1[j].w), f2u(sh.q0[j].w));
+        v[VTX_LI0] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        v[VTX_LI1] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    };
+    if (sc.lds_wnodes) bvh_stream_wide<CENSUS, true, true>(sc, n, 0.9999f, fetch, emit, &cn, &ct);
+    else bvh_stream_wide<CENSUS, true, false>(sc, n, 0.9999f, fetch, emit, &cn, &ct);
+    if (CENSUS) census_add(census, 2, cn, ct);
+}
+
 // The two walkers of the guided integrator in ONE launch: the shadow rays of round r and the bounce rays of round r + 1
 // both exist once shade(r) has run and do not depend on each other. Late rounds and small waves (one GPU's share of a
 // multi-GPU job) are bound by launch count and by the tail of each launch, not by work: two launches per round instead of

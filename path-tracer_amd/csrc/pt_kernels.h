@@ -353,8 +353,8 @@ __global__ __launch_bounds__(kBlock, PT_STREAM_WAVES) void k_extend_stream(Scene
         hit.tb[i] = make_float4(h.th.t, h.th.b0, h.th.b1, h.th.b2);
         hit.prim[i] = make_uint2(h.prim, h.tag);
     };
-    if (sc.lds_wnodes) bvh_stream_wide<CENSUS, true>(sc, n, fetch, emit, &cn, &ct);
-    else bvh_stream_wide<CENSUS, false>(sc, n, fetch, emit, &cn, &ct);
+    if (sc.lds_wnodes) bvh_stream_wide<CENSUS, false, true>(sc, n, f_inf(), fetch, emit, &cn, &ct);
+    else bvh_stream_wide<CENSUS, false, false>(sc, n, f_inf(), fetch, emit, &cn, &ct);
     if (CENSUS) census_add(census, 0, cn, ct);
 }
 

@@ -662,7 +662,12 @@ int ptgpu_scene_create(ptgpu_ctx* c, const ptgpu_scene_desc* desc) {
         PT_SET_LDS(k_occlude_path)
         PT_SET_LDS(k_occlude_splat)
         PT_SET_LDS(k_occlude_guided)
+        PT_SET_LDS(k_walk_guided)
 #undef PT_SET_LDS
+        HIP_TRY(hipFuncSetAttribute((const void*)k_extend_stream<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_w));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_extend_stream<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_w));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_occlude_guided_stream<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_w));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_occlude_guided_stream<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_w));
         HIP_TRY(hipFuncSetAttribute((const void*)k_occluded_batch<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b));
         HIP_TRY(hipFuncSetAttribute((const void*)k_occluded_batch<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_w));
     }

@@ -161,10 +161,10 @@ def furnace_scene(kind: str = "plain"):
     return pt.SceneDescription(meshes, mats)
 
 
-def deep_chain_scene(n: int, base: float):
+def deep_chain_scene(n: int, base: float, lit: bool = False):
     """n small triangles on the space diagonal at geometrically growing distances (base^i): the SAH build peels them off a
     few at a time, which makes the BVH as deep as the reference's 64-entry traversal stack allows (180 / 1.6 -> depth 59,
-    200 / 1.5 -> depth 64). Returns (scene, centroids, sizes)."""
+    200 / 1.5 -> depth 64). lit: grey diffuse emitters instead of triangles without a material. Returns (scene, centroids, sizes)."""
     pts, tris, cen, size = [], [], [], []
     for i in range(n):
         s = base ** i
@@ -173,7 +173,10 @@ def deep_chain_scene(n: int, base: float):
         tris.append([3 * i, 3 * i + 1, 3 * i + 2])
         cen.append([s + e / 3, s + e / 3, s + e / 3])
         size.append(e)
-    sc = pt.SceneDescription([{"points": np.array(pts, dtype=np.float32), "triangles": np.array(tris, dtype=np.uint32), "material_index": -1}], [])
+    mesh = {"points": np.array(pts, dtype=np.float32), "triangles": np.array(tris, dtype=np.uint32), "material_index": 0 if lit else -1}
+    if lit:
+        mesh["emission"] = GREY
+    sc = pt.SceneDescription([mesh], [(pt.MAT_LAMBERTIAN, 0.0, GREY, (0, 0, 0, 0))] if lit else [])
     return sc, np.array(cen, dtype=np.float64), np.array(size, dtype=np.float64)
 
 

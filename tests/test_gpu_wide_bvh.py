@@ -137,6 +137,48 @@ def test_renders_do_not_depend_on_the_traversal(wide_ctx, name, kind):
     np.testing.assert_allclose(fa, fb, rtol=1e-9, atol=1e-12)
 
 
+def test_streamed_occlusion_of_the_guided_integrator(wide_ctx):
+    """Batches above the fused walker's limit (786 432 paths) with the wide walk run k_occlude_guided_stream: the first
+    wave (no tree yet, so no dependence on the order of the collector's atomics) must trace the rays and give the film of the
+    binary walk's kernels."""
+    sc = pt.LoadedScene("veach-bidir", resx=1024, resy=800, max_depth=6)
+    wide_ctx.load(sc)
+    integ = pt.IntegratorDesc.from_buffer_copy(sc.integrator)
+    integ.kind = pt.INTEGRATOR_GUIDED
+    out = []
+    for wide in (False, True):
+        wide_ctx.set_traversal(wide)
+        f, s, st = wide_ctx.render(integ, 1)
+        out.append((f * s, st))
+    (fa, sa), (fb, sb) = out
+    assert sa["shadow_rays"] > 0
+    assert sa["extend_rays"] == sb["extend_rays"] and sa["shadow_rays"] == sb["shadow_rays"] and sa["segments"] == sb["segments"]
+    np.testing.assert_allclose(fa, fb, rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize("kind", [pt.INTEGRATOR_PATH, pt.INTEGRATOR_LIGHTPATH, pt.INTEGRATOR_GUIDED])
+def test_renders_in_a_59_level_tree(wide_ctx, kind):
+    """The integrators' walkers with more than 64 KB of traversal stack per workgroup (every one of them needs the raised
+    limit, the streamed and the fused ones included): a chain of emissive triangles seen from the origin, along the diagonal
+    they sit on. One segment per path: the first hits and their shadow rays start at the small triangles near the origin.
+    (Longer paths leave from triangles at 1e30 and beyond, where the triangle test's products overflow f32 and the
+    reference's own hits are NaNs; which NaN wins depends on details of the walk that no parity claim covers.)"""
+    sc, _, _ = su.deep_chain_scene(180, 1.6, lit=True)
+    o = ob.OracleScene(sc)
+    wide_ctx.set_scene(sc)
+    assert su.bvh_depth(wide_ctx.scene_bvh()[0]) == 59
+    cam = pt.make_camera(su.IDENTITY, 120.0, 96, 96)
+    wide_ctx.set_camera(cam)
+    integ = pt.make_integrator(kind, 1, pt.MODE_MIS)
+    spp = 1 if kind == pt.INTEGRATOR_GUIDED else 2  # guided: the first wave, as in test_guided_first_wave_equals_oracle
+    _, _, cst = o.render(cam, integ, spp)
+    assert cst["extend_rays"] > 0 and cst["shadow_rays"] > 0
+    for wide in (False, True):
+        wide_ctx.set_traversal(wide)
+        _, _, st = wide_ctx.render(integ, spp)
+        assert (st["extend_rays"], st["shadow_rays"]) == (cst["extend_rays"], cst["shadow_rays"]), wide
+
+
 def test_set_traversal_needs_a_scene():
     ctx = pt.Context(0)
     with pytest.raises(pt.PtError, match="no scene"):
