@@ -674,11 +674,14 @@ PT_D void bvh_stream_wide(const SceneDev& sc, uint32_t n, const float ray_end_t,
     best.th.t = ray_end_t;
     best.th.b0 = best.th.b1 = best.th.b2 = 0.0f;
     for (;;) {
-        if (have_ray && !have) {  // this lane's ray is done
-            if (!(best.th.t != ray_end_t)) best.prim = kNoHit;  // bvh.rs:137
-            if (!ANY_HIT && best.prim != kNoHit) best.tag = f2u(sc.tri_v[3 * best.prim + 2].w);
-            emit(j, best);
-            have_ray = false;
+        const bool done = have_ray && !have;  // this lane's ray is finished
+        if (__any(done)) {  // emit is called by the whole wave (it may add to the film wave-wide), `done` marks its lanes
+            if (done) {
+                if (!(best.th.t != ray_end_t)) best.prim = kNoHit;  // bvh.rs:137
+                if (!ANY_HIT && best.prim != kNoHit) best.tag = f2u(sc.tri_v[3 * best.prim + 2].w);
+            }
+            emit(done, j, best);
+            if (done) have_ray = false;
         }
         const unsigned long long free_mask = __ballot(!have_ray);
         const uint32_t n_free = (uint32_t)__popcll(free_mask);

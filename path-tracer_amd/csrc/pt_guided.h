@@ -918,8 +918,8 @@ __global__ __launch_bounds__(kBlock, PT_STREAM_WAVES) void k_occlude_guided_stre
         o = mk3(a.x, a.y, a.z);
         d = mk3(q.x, q.y, q.z) - o;  // Scene::occluded: unnormalised segment, t_max 0.9999
     };
-    const auto emit = [&](uint32_t j, const Hit& h) {
-        if (h.prim == kNoHit) return;
+    const auto emit = [&](bool done, uint32_t j, const Hit& h) {
+        if (!done || h.prim == kNoHit) return;
         float4* v = gp.vtx.at(f2u(sh.q1[j].w), f2u(sh.q0[j].w));
         v[VTX_LI0] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         v[VTX_LI1] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);

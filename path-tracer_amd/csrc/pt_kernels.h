@@ -348,7 +348,8 @@ __global__ __launch_bounds__(kBlock, PT_STREAM_WAVES) void k_extend_stream(Scene
         o = mk3(a.x, a.y, a.z);
         d = mk3(b.x, b.y, b.z);
     };
-    const auto emit = [&](uint32_t j, const Hit& h) {
+    const auto emit = [&](bool done, uint32_t j, const Hit& h) {
+        if (!done) return;
         const uint32_t i = slot_of_index(j, n_bottom, capacity);
         hit.tb[i] = make_float4(h.th.t, h.th.b0, h.th.b1, h.th.b2);
         hit.prim[i] = make_uint2(h.prim, h.tag);
@@ -614,6 +615,50 @@ __global__ __launch_bounds__(kBlock, WIDE ? PT_WIDE_WAVES : 8) void k_occlude_pa
         }
         film_add_rgb_wave(rp.film, pixel, rgb, to_film, sc.guards);
     }
+    if (CENSUS) census_add(census, 2, cn, ct);
+}
+
+// The same over the shadow queue as a stream (bvh_stream_wide), for the four-wide walk of large scenes. Film adds of
+// paths that end here go out as their rays finish, wave-wide as above (another order of the same atomic adds).
+template <bool CENSUS>
+__global__ __launch_bounds__(kBlock, PT_STREAM_WAVES) void k_occlude_path_stream(SceneDev sc, RenderParams rp, PathCols st, ShadowCols sh, const RoundCounters* cnt, unsigned long long* census) {
+    const uint32_t n = cnt->n_shadow;
+    if (blockIdx.x * blockDim.x >= n) return;
+    bvh_stage_nodes<true>(sc);
+    uint32_t cn = 0, ct = 0;
+    const auto fetch = [&](uint32_t j, V3& o, V3& d) {
+        const float4 a = sh.q0[j], b = sh.q1[j];
+        o = mk3(a.x, a.y, a.z);
+        d = mk3(b.x, b.y, b.z) - o;  // Scene::occluded: unnormalised segment, t_max 0.9999
+    };
+    const auto emit = [&](bool done, uint32_t j, const Hit& h) {
+        bool to_film = false;
+        uint32_t pixel = 0;
+        double rgb[3] = {0.0, 0.0, 0.0};
+        if (done) {
+            const bool occ = h.prim != kNoHit;
+            const uint32_t target = f2u(sh.q0[j].w);
+            const uint32_t slot = target & ~kTerminalBit;
+            if (target & kTerminalBit) {
+                Spec L = load_spec(st.L0, st.L1, slot);
+                if (!occ) L = L + load_spec(sh.q2, sh.q3, j);
+                if (!spec_is_black(L)) {
+                    const uint4 rp4 = st.rng_px[slot];
+                    const uint32_t flags = f2u(st.d_flags[slot].w);
+                    const Lambdas wl = load_lambdas(rp.lambda_tab, rp4.w, true);
+                    spec_to_rgb(L, wl, (flags & FLAG_SECONDARY_TERMINATED) != 0, sc.cie_xyz, rgb);
+                    pixel = rp4.z;
+                    to_film = true;
+                }
+            } else if (!occ) {
+                const Spec L = load_spec(st.L0, st.L1, slot) + load_spec(sh.q2, sh.q3, j);
+                store_spec(st.L0, st.L1, slot, L);
+            }
+        }
+        film_add_rgb_wave(rp.film, pixel, rgb, to_film, sc.guards);
+    };
+    if (sc.lds_wnodes) bvh_stream_wide<CENSUS, true, true>(sc, n, 0.9999f, fetch, emit, &cn, &ct);
+    else bvh_stream_wide<CENSUS, true, false>(sc, n, 0.9999f, fetch, emit, &cn, &ct);
     if (CENSUS) census_add(census, 2, cn, ct);
 }
 

@@ -666,6 +666,8 @@ int ptgpu_scene_create(ptgpu_ctx* c, const ptgpu_scene_desc* desc) {
 #undef PT_SET_LDS
         HIP_TRY(hipFuncSetAttribute((const void*)k_extend_stream<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_w));
         HIP_TRY(hipFuncSetAttribute((const void*)k_extend_stream<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_w));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_occlude_path_stream<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_w));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_occlude_path_stream<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_w));
         HIP_TRY(hipFuncSetAttribute((const void*)k_occlude_guided_stream<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_w));
         HIP_TRY(hipFuncSetAttribute((const void*)k_occlude_guided_stream<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_w));
         HIP_TRY(hipFuncSetAttribute((const void*)k_occluded_batch<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b));
@@ -881,12 +883,16 @@ int ptgpu_set_batch_paths(ptgpu_ctx* c, uint32_t n_paths) {
 
 namespace {
 
+// The four-wide walks take their queue as a stream (lanes refilled as their rays finish: veach-mis extend 31.2 -> 29.0 ms
+// per 128 spp, guided-large 327 -> 342 Msamples/s with the occlusion streamed as well); the binary walk of small scenes
+// does not (most rays finish inside one round of the while-while loop: nothing to refill, Cornell extend +13 %).
+// PTGPU_STREAM_WALK=0: one ray per lane and trip everywhere.
+bool stream_walk_enabled() {
+    static const bool on = getenv("PTGPU_STREAM_WALK") ? atoi(getenv("PTGPU_STREAM_WALK")) != 0 : true;
+    return on;
+}
 void launch_extend(ptgpu_ctx* c, int grid, const PathCols& A, const HitCols& H, const RoundCounters* cnt, const uint32_t* top = nullptr) {
-    // The four-wide closest-hit walk takes its queue as a stream (lanes refilled as their rays finish: veach-mis extend
-    // 31.2 -> 29.0 ms per 128 spp); the binary walk of small scenes does not (most rays finish inside one round of the
-    // while-while loop: nothing to refill, Cornell extend +13 %). PTGPU_STREAM_WALK=0: one ray per lane and trip everywhere.
-    static const bool stream_walk = getenv("PTGPU_STREAM_WALK") ? atoi(getenv("PTGPU_STREAM_WALK")) != 0 : true;
-    if (stream_walk && c->wide) {
+    if (stream_walk_enabled() && c->wide) {
         if (c->census_on) PT_LAUNCH_WALK(c, k_extend_stream<true>, grid, c->scene, A, H, cnt, c->d_census.p, top, c->capacity);
         else PT_LAUNCH_WALK(c, k_extend_stream<false>, grid, c->scene, A, H, cnt, c->d_census.p, top, c->capacity);
         return;
@@ -975,6 +981,9 @@ int run_batch_path_like(ptgpu_ctx* c, bool light, const RenderParams& rp, uint32
             if (light) {
                 if (c->census_on) PT_LAUNCH_WALK(c, PT_WALKER(c, k_occlude_splat, true), grid, c->scene, rp, S, cnt + round + 1, c->d_census.p);
                 else PT_LAUNCH_WALK(c, PT_WALKER(c, k_occlude_splat, false), grid, c->scene, rp, S, cnt + round + 1, c->d_census.p);
+            } else if (stream_walk_enabled() && c->wide) {
+                if (c->census_on) PT_LAUNCH_WALK(c, k_occlude_path_stream<true>, grid, c->scene, rp, B, S, cnt + round + 1, c->d_census.p);
+                else PT_LAUNCH_WALK(c, k_occlude_path_stream<false>, grid, c->scene, rp, B, S, cnt + round + 1, c->d_census.p);
             } else {
                 if (c->census_on) PT_LAUNCH_WALK(c, PT_WALKER(c, k_occlude_path, true), grid, c->scene, rp, B, S, cnt + round + 1, c->d_census.p);
                 else PT_LAUNCH_WALK(c, PT_WALKER(c, k_occlude_path, false), grid, c->scene, rp, B, S, cnt + round + 1, c->d_census.p);
