@@ -366,6 +366,11 @@ PT_HD bool ray_triangle(V3 ro, const RayShear& rs, V3 p0, V3 p1, V3 p2, float ma
 // triangle below that node: the reference would reject them all (geom.rs:261-268). Skipping the node changes nothing.
 // (The full slab entry max(t_x, t_y, t_z) would cull a little more, but the other two axes have no such bound in
 // floating point: barycentrics are ill-conditioned at grazing incidence.)
+// The test is written !(t_dom > best.t * (1 + 32 eps)): a NaN best.t culls nothing. The reference's triangle test
+// accepts a NaN hit (its rejections are all comparisons, false on NaN; it happens when |p - o| exceeds ~1e19 and the
+// edge functions overflow), after which it still visits every box: so does this walk. What the cull cannot follow is
+// the reverse order: a finite hit first, then a triangle in a farther box whose test comes out NaN and REPLACES it in
+// the reference. Scenes that reach across 1e19 units lose bit parity there (parity).
 //
 // Shape of the loop (CDNA4): the order in which nodes are visited does not depend on what the ray hits (only whether a node is skipped
 // does). That allows a "while-while" walk — every lane first descends boxes until it stands on
@@ -502,7 +507,7 @@ PT_D Hit bvh_intersect_wide(const SceneDev& sc, V3 o, V3 d, float ray_end_t, uin
                     t_dom = shear.kz == 2 ? t0 : t_dom;
                     tmin = fmaxf(tmin, t0);
                     tmax = fminf(tmax, t1);
-                    if ((uint32_t)c < n_children && (0.0f <= tmin) && (tmin <= tmax) && (t_dom <= best.th.t * kCullSlack)) hit_mask |= 1u << c;
+                    if ((uint32_t)c < n_children && (0.0f <= tmin) && (tmin <= tmax) && !(t_dom > best.th.t * kCullSlack)) hit_mask |= 1u << c;
                 }
                 if (COUNT) (*n_nodes_visited) += n_children;
 #pragma unroll
@@ -584,7 +589,7 @@ PT_D Hit bvh_intersect_binary(const SceneDev& sc, V3 o, V3 d, float ray_end_t, u
                 tmin = fmaxf(tmin, t0);
                 tmax = fminf(tmax, t1);
             }
-            if ((0.0f <= tmin) && (tmin <= tmax) && (t_dom <= best.th.t * kCullSlack)) {
+            if ((0.0f <= tmin) && (tmin <= tmax) && !(t_dom > best.th.t * kCullSlack)) {
                 const uint32_t ntris = meta & 0xffffu;
                 if (ntris == 0) {
                     const bool neg = ((neg_mask >> (meta >> 16)) & 1u) != 0u;
@@ -751,7 +756,7 @@ PT_D void bvh_stream_wide(const SceneDev& sc, uint32_t n, const float ray_end_t,
                     t_dom = shear.kz == 2 ? t0 : t_dom;
                     tmin = fmaxf(tmin, t0);
                     tmax = fminf(tmax, t1);
-                    if ((uint32_t)c < n_children && (0.0f <= tmin) && (tmin <= tmax) && (t_dom <= best.th.t * kCullSlack)) hit_mask |= 1u << c;
+                    if ((uint32_t)c < n_children && (0.0f <= tmin) && (tmin <= tmax) && !(t_dom > best.th.t * kCullSlack)) hit_mask |= 1u << c;
                 }
                 if (COUNT) (*n_nodes_visited) += n_children;
 #pragma unroll

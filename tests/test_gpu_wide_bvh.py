@@ -160,16 +160,16 @@ def test_streamed_occlusion_of_the_guided_integrator(wide_ctx):
 def test_renders_in_a_59_level_tree(wide_ctx, kind):
     """The integrators' walkers with more than 64 KB of traversal stack per workgroup (every one of them needs the raised
     limit, the streamed and the fused ones included): a chain of emissive triangles seen from the origin, along the diagonal
-    they sit on. One segment per path: the first hits and their shadow rays start at the small triangles near the origin.
-    (Longer paths leave from triangles at 1e30 and beyond, where the triangle test's products overflow f32 and the
-    reference's own hits are NaNs; which NaN wins depends on details of the walk that no parity claim covers.)"""
+    they sit on. path and lightpath at depth 4: later segments leave from triangles at 1e30 and beyond, where the triangle
+    test's products overflow f32 and the reference's own hits are NaNs; a NaN closest hit must switch the distance cull
+    off as it does in the reference (pt_device.h, "Culling"), or ray counts fall short of the oracle's by half."""
     sc, _, _ = su.deep_chain_scene(180, 1.6, lit=True)
     o = ob.OracleScene(sc)
     wide_ctx.set_scene(sc)
     assert su.bvh_depth(wide_ctx.scene_bvh()[0]) == 59
     cam = pt.make_camera(su.IDENTITY, 120.0, 96, 96)
     wide_ctx.set_camera(cam)
-    integ = pt.make_integrator(kind, 1, pt.MODE_MIS)
+    integ = pt.make_integrator(kind, 1 if kind == pt.INTEGRATOR_GUIDED else 4, pt.MODE_MIS)
     spp = 1 if kind == pt.INTEGRATOR_GUIDED else 2  # guided: the first wave, as in test_guided_first_wave_equals_oracle
     _, _, cst = o.render(cam, integ, spp)
     assert cst["extend_rays"] > 0 and cst["shadow_rays"] > 0
