@@ -848,5 +848,35 @@ __global__ __launch_bounds__(kBlock) void k_occlude_splat(SceneDev sc, RenderPar
     }
     if (CENSUS) census_add(census, 2, cn, ct);
 }
+// The same over the connection queue as a stream (bvh_stream_wide), for the four-wide walk of large scenes.
+template <bool CENSUS>
+__global__ __launch_bounds__(kBlock, PT_STREAM_WAVES) void k_occlude_splat_stream(SceneDev sc, RenderParams rp, ShadowCols sh, const RoundCounters* cnt, unsigned long long* census) {
+    const uint32_t n = cnt->n_shadow;
+    if (blockIdx.x * blockDim.x >= n) return;
+    bvh_stage_nodes<true>(sc);
+    const double* r = reinterpret_cast<const double*>(sh.q2);
+    double* film = rp.film + (size_t)(blockIdx.x % rp.film_copies) * kFilmStride * rp.n_pixels;
+    uint32_t cn = 0, ct = 0;
+    const auto fetch = [&](uint32_t j, V3& o, V3& d) {
+        const float4 a = sh.q0[j], b = sh.q1[j];
+        o = mk3(a.x, a.y, a.z);
+        d = mk3(b.x, b.y, b.z) - o;  // Scene::occluded: unnormalised segment, t_max 0.9999
+    };
+    const auto emit = [&](bool done, uint32_t j, const Hit& h) {
+        const bool visible = done && h.prim == kNoHit;
+        uint32_t pixel = 0;
+        double rgb[3] = {0.0, 0.0, 0.0};
+        if (visible) {
+            rgb[0] = r[3 * (size_t)j];
+            rgb[1] = r[3 * (size_t)j + 1];
+            rgb[2] = r[3 * (size_t)j + 2];
+            pixel = f2u(sh.q0[j].w);
+        }
+        film_add_rgb_wave(film, pixel, rgb, visible, sc.guards);
+    };
+    if (sc.lds_wnodes) bvh_stream_wide<CENSUS, true, true>(sc, n, 0.9999f, fetch, emit, &cn, &ct);
+    else bvh_stream_wide<CENSUS, true, false>(sc, n, 0.9999f, fetch, emit, &cn, &ct);
+    if (CENSUS) census_add(census, 2, cn, ct);
+}
 
 }  // namespace pt

@@ -668,6 +668,8 @@ int ptgpu_scene_create(ptgpu_ctx* c, const ptgpu_scene_desc* desc) {
         HIP_TRY(hipFuncSetAttribute((const void*)k_extend_stream<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_w));
         HIP_TRY(hipFuncSetAttribute((const void*)k_occlude_path_stream<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_w));
         HIP_TRY(hipFuncSetAttribute((const void*)k_occlude_path_stream<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_w));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_occlude_splat_stream<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_w));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_occlude_splat_stream<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_w));
         HIP_TRY(hipFuncSetAttribute((const void*)k_occlude_guided_stream<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_w));
         HIP_TRY(hipFuncSetAttribute((const void*)k_occlude_guided_stream<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_w));
         HIP_TRY(hipFuncSetAttribute((const void*)k_occluded_batch<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b));
@@ -978,7 +980,10 @@ int run_batch_path_like(ptgpu_ctx* c, bool light, const RenderParams& rp, uint32
         }
         {
             StageTimer t(c, PTGPU_STAGE_OCCLUDE);
-            if (light) {
+            if (light && stream_walk_enabled() && c->wide) {
+                if (c->census_on) PT_LAUNCH_WALK(c, k_occlude_splat_stream<true>, grid, c->scene, rp, S, cnt + round + 1, c->d_census.p);
+                else PT_LAUNCH_WALK(c, k_occlude_splat_stream<false>, grid, c->scene, rp, S, cnt + round + 1, c->d_census.p);
+            } else if (light) {
                 if (c->census_on) PT_LAUNCH_WALK(c, PT_WALKER(c, k_occlude_splat, true), grid, c->scene, rp, S, cnt + round + 1, c->d_census.p);
                 else PT_LAUNCH_WALK(c, PT_WALKER(c, k_occlude_splat, false), grid, c->scene, rp, S, cnt + round + 1, c->d_census.p);
             } else if (stream_walk_enabled() && c->wide) {
