@@ -250,7 +250,7 @@ int ptgpu_guard_counts(ptgpu_ctx* ctx, uint64_t out[4]);
  * node; leaves, triangle order and the per-octant visit order are the binary tree's), which reports the same hits bit
  * for bit at a quarter of the loop trips. Fails with PTGPU_E_LIMIT for a scene whose tree has no wide image (a leaf
  * of more than 128 triangles). Takes effect from the next call on; ptgpu_scene_create resets it to the default:
- * wide for trees of more than 1 MB of binary nodes, where it is faster (PTGPU_BVH_WIDE=0|1 in the environment overrides). ptgpu_get_traversal returns the mode in use. */
+ * wide for trees of more than 256 KB of binary nodes, where it is faster (PTGPU_BVH_WIDE=0|1 in the environment overrides). ptgpu_get_traversal returns the mode in use. */
 int ptgpu_set_traversal(ptgpu_ctx* ctx, int wide);
 int ptgpu_get_traversal(ptgpu_ctx* ctx);
 /* Paths kept in flight per batch (state SoA size); 0 restores the default. */
