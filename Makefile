@@ -8,7 +8,7 @@ HIPFLAGS = -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -munsafe-fp-at
 CSRC = $(PKG)/csrc
 GPU_DEPS = $(wildcard $(CSRC)/*.h $(CSRC)/*.inc) include/ptgpu.h
 
-all: $(LIB)/libptgpu.so $(LIB)/libpthost.so $(LIB)/pt oracle
+all: $(LIB)/libptgpu.so $(LIB)/libpthost.so $(LIB)/pt $(LIB)/calib_fetch oracle
 
 $(LIB)/libptgpu.so: $(CSRC)/ptgpu.hip $(CSRC)/bvh_build.cpp $(CSRC)/sdtree_host.cpp $(GPU_DEPS)
 	mkdir -p $(LIB)
@@ -20,6 +20,11 @@ $(LIB)/libpthost.so: $(PKG)/host/pthost.cpp include/pthost.h include/ptgpu.h $(C
 
 $(LIB)/pt: $(PKG)/host/pt_main.cpp $(LIB)/libpthost.so $(LIB)/libptgpu.so
 	$(CXX) -O2 -std=c++17 -Wall -o $@ $(PKG)/host/pt_main.cpp -L$(LIB) -lpthost -lptgpu -Wl,-rpath,'$$ORIGIN'
+
+# FETCH_SIZE calibration micro-benchmark (tools/gpu_calib_fetch.sh); a measuring tool, not part of the product
+$(LIB)/calib_fetch: tools/calib_fetch.hip
+	mkdir -p $(LIB)
+	$(HIPCC) -O3 -std=c++17 --offload-arch=gfx950 -o $@ tools/calib_fetch.hip
 
 oracle:
 	$(MAKE) -C oracle
