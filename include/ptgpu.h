@@ -188,6 +188,17 @@ int ptgpu_guided_probe(ptgpu_ctx* ctx, const float* points, const float* query_s
 int ptgpu_guided_record_batch(ptgpu_ctx* ctx, const float* records, uint32_t n);
 /* Builds the tree of the next wave now (what the next ptgpu_guided_wave would do first); that call then skips it. */
 int ptgpu_guided_refine(ptgpu_ctx* ctx);
+/* Parity hook for the back-to-front loop of PathGuidingIntegrator::render (path_guiding/mod.rs:106-115): with capture on,
+ * every ptgpu_guided_wave keeps what its production kernels (k_guide_scan, then k_guide_locate) made of each
+ * `guider.add(l.average() / v.wi_pdf, v.p, v.wi, sampler)` call — 14 words per record, floats as bits:
+ *   {p.xyz, wi.xyz, radiance, u0, u1, u2 (the stochastic filter's draws, stree.rs:195-199), spatial leaf id the record
+ *    went to (0xffffffff with PTGPU_DIRECT_SPLAT), pixel (x + y * resx), sample pass (0xffffffff unless the image is a
+ *    whole number of 16 x 16 tiles and the render is unsharded), index of the vertex in its path}.
+ * ptgpu_guided_captured_records returns the records of the last wave traced (all of them counted in *n_records_out,
+ * at most capacity_records copied; out_words may be NULL to ask for the count). Waves traced with capture on wait for
+ * the device and copy the queue through pageable memory: a test path. */
+int ptgpu_guided_capture_records(ptgpu_ctx* ctx, int enabled);
+int ptgpu_guided_captured_records(ptgpu_ctx* ctx, uint32_t* out_words, uint64_t capacity_records, uint64_t* n_records_out);
 
 /* Parity hooks (no reference counterpart as an API; they expose Scene::intersect_t -> Bvh::intersect,
  * pt/src/bvh.rs:86-142, and Scene::occluded, pt/src/scene.rs:229-235, on caller-supplied rays).

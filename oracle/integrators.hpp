@@ -465,6 +465,7 @@ inline void guided_wave_passes(const Scene& scene, const Camera& cam, const Inte
                         const PathVertex& v = path[vi];
                         if (!v.is_specular) {
                             float r = l.average() / v.wi_pdf;
+                            record_key() = RecordKey{(uint32_t)(ix + iy * film.w), (uint32_t)i, (uint32_t)vi};
                             guider.stree.record(v.p, v.wi, r, sampler);
                         }
                         l = l * v.f;

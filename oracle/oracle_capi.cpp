@@ -291,6 +291,7 @@ int orc_dtree_exercise(const float* pts2, const float* rad, uint32_t n, int filt
 // ---- SD-tree handle: the same tree on both sides (tests/test_gpu_sdtree.py). Layout of the flat arrays = ptgpu_guided_tree_download.
 struct orc_sdtree {
     Guider guider;
+    RecordLog log;
     std::vector<uint32_t> leaf_id;  // per spatial node (0xffffffff for interior), numbered in node order like the product's host tree
     void renumber() {
         leaf_id.assign(guider.stree.nodes.size(), 0xffffffffu);
@@ -460,6 +461,20 @@ void orc_sdtree_record(orc_sdtree* t, const float* records, uint32_t n) {
         const float* r = records + 10 * (size_t)i;
         t->guider.stree.record_drawn(v3(r[0], r[1], r[2]), v3(r[3], r[4], r[5]), r[6], r[7], r[8], r[9], unused);
     }
+}
+// Guider::add's arguments (mod.rs:106-115) of the waves traced while the log is on: 14 words per record in the layout of
+// ptgpu_guided_captured_records (p, wi, radiance, u0, u1, u2, leaf id, pixel, pass, vertex). Returns the record count.
+void orc_sdtree_log_records(orc_sdtree* t, int enable) {
+    t->log.words.clear();
+    t->guider.stree.log = enable ? &t->log : nullptr;
+}
+uint64_t orc_sdtree_logged_records(orc_sdtree* t, uint32_t* out, uint64_t capacity_records) {
+    const uint64_t n = t->log.words.size() / 14;
+    for (uint64_t i = 0; i < n && i < capacity_records; i++) {
+        std::memcpy(out + 14 * i, t->log.words.data() + 14 * i, 14 * sizeof(uint32_t));
+        out[14 * i + 10] = t->leaf_id[t->log.words[14 * i + 10]];  // leaf node -> leaf id (valid until the next refinement)
+    }
+    return n;
 }
 void orc_sdtree_new_iteration(orc_sdtree* t, uint32_t iteration) {  // Guider::new_iteration's refinement (mod.rs:372-383)
     t->guider.stree.new_iteration(t->guider.directional_threshold, t->guider.spatial_threshold, iteration);

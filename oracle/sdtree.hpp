@@ -4,6 +4,7 @@
 // The reference guards each collector with a Mutex; the oracle is run single-threaded per wave pass or
 // with a lock per leaf (see integrators.hpp), so plain structs suffice here.
 #pragma once
+#include <cstring>
 #include <mutex>
 #include <vector>
 
@@ -264,6 +265,21 @@ struct DTree {
     }
 };
 
+// Test hook (tests/test_gpu_sdtree.py): the arguments of every Guider::add / STree::record call that passes the early
+// return (mod.rs:106-115, stree.rs:102-116) with the stochastic filter's three draws and the leaf that received it,
+// keyed by the path that made it. 14 words per record: p, wi, radiance, u0, u1, u2, leaf NODE, pixel, pass, vertex.
+struct RecordLog {
+    std::mutex m;
+    std::vector<uint32_t> words;
+};
+struct RecordKey {
+    uint32_t pixel = 0, pass = 0, vertex = 0;
+};
+inline RecordKey& record_key() {  // set by guided_wave_passes before each record() call of its thread
+    thread_local RecordKey k;
+    return k;
+}
+
 struct STreeNode {  // stree.rs:12-19
     DTree sampler, collector;
     size_t left = 0, right = 0, split_axis = 0, depth = 0;
@@ -276,6 +292,7 @@ struct STree {
     std::vector<STreeNode> nodes;
     B3 bounds;
     Filter filter = Filter::Stochastic;
+    RecordLog* log = nullptr;  // not owned
 
     void init(B3 scene_bounds, Filter spatial, Filter directional) {  // stree.rs:21-34
         nodes.clear();
@@ -316,10 +333,11 @@ struct STree {
         std::lock_guard<std::mutex> g(*nodes[ni].lock);
         nodes[ni].collector.record(p2, radiance, w, sampler);
     }
-    void record_nearest(V3 p3, V2 p2, float radiance, Sampler& sampler) {
+    size_t record_nearest(V3 p3, V2 p2, float radiance, Sampler& sampler) {
         B3 lb;
         size_t ni = leaf(p3, &lb);
         node_record(ni, p2, radiance, 1.0f, sampler);
+        return ni;
     }
     void record_box_recursive(B3 node_bounds, B3 footprint, V2 p2, float radiance, size_t ni, Sampler& sampler) {  // stree.rs:134-172
         for (size_t i = 0; i < 2; i++) {
@@ -342,17 +360,26 @@ struct STree {
         B3 footprint = B3::around(p3, lb.extent()).clamp(bounds.min, bounds.max);
         record_box_recursive(bounds, footprint, p2, radiance, 0, sampler);
     }
-    void record_stochastic(V3 p3, V2 p2, float radiance, Sampler& sampler) {  // stree.rs:186-201
+    void record_stochastic(V3 p3, V3 wi, V2 p2, float radiance, Sampler& sampler) {  // stree.rs:186-201
         float u0 = sampler.sample1d(), u1 = sampler.sample1d(), u2 = sampler.sample1d();
-        record_stochastic_drawn(p3, p2, radiance, u0, u1, u2, sampler);
+        size_t ni = record_stochastic_drawn(p3, p2, radiance, u0, u1, u2, sampler);
+        if (log) {
+            const RecordKey k = record_key();
+            const float f[10] = {p3.x, p3.y, p3.z, wi.x, wi.y, wi.z, radiance, u0, u1, u2};
+            uint32_t w[14];
+            std::memcpy(w, f, sizeof(f));
+            w[10] = (uint32_t)ni; w[11] = k.pixel; w[12] = k.pass; w[13] = k.vertex;
+            std::lock_guard<std::mutex> g(log->m);
+            log->words.insert(log->words.end(), w, w + 14);
+        }
     }
-    // the body of record_stochastic after its three draws (split off so that a test can replay given draws)
-    void record_stochastic_drawn(V3 p3, V2 p2, float radiance, float u0, float u1, float u2, Sampler& sampler) {
+    // the body of record_stochastic after its three draws (split off so that a test can replay given draws); -> leaf node
+    size_t record_stochastic_drawn(V3 p3, V2 p2, float radiance, float u0, float u1, float u2, Sampler& sampler) {
         B3 lb;
         leaf(p3, &lb);
         B3 jitter = B3::around(p3, lb.extent());
         V3 q = bounds.clip(jitter.lerp(v3(u0, u1, u2)));
-        record_nearest(q, p2, radiance, sampler);
+        return record_nearest(q, p2, radiance, sampler);
     }
     // STree::record (stree.rs:102-116) with the stochastic filter's draws supplied by the caller
     void record_drawn(V3 p, V3 wi, float radiance, float u0, float u1, float u2, Sampler& sampler) {
@@ -367,7 +394,7 @@ struct STree {
         switch (filter) {
             case Filter::Nearest: record_nearest(p, p2, radiance, sampler); break;
             case Filter::Box: record_box(p, p2, radiance, sampler); break;
-            case Filter::Stochastic: record_stochastic(p, p2, radiance, sampler); break;
+            case Filter::Stochastic: record_stochastic(p, wi, p2, radiance, sampler); break;
         }
     }
     void subdivide_nodes(float base, size_t iteration) {  // stree.rs:55-101

@@ -89,7 +89,7 @@ PTGPU_SYMBOLS = [
     "ptgpu_trace_batch", "ptgpu_occluded_batch", "ptgpu_scene_info", "ptgpu_scene_bvh", "ptgpu_set_profiling",
     "ptgpu_set_batch_paths", "ptgpu_kernel_times", "ptgpu_set_census", "ptgpu_census", "ptgpu_guided_selfcheck",
     "ptgpu_trace_batch_noalloc", "ptgpu_guided_tree_info", "ptgpu_guided_tree_download", "ptgpu_guided_probe",
-    "ptgpu_guided_record_batch", "ptgpu_guided_refine", "ptgpu_guard_counts", "ptgpu_film_device", "ptgpu_set_traversal",
+    "ptgpu_guided_record_batch", "ptgpu_guided_refine", "ptgpu_guided_capture_records", "ptgpu_guided_captured_records", "ptgpu_guard_counts", "ptgpu_film_device", "ptgpu_set_traversal",
     "ptgpu_get_traversal", "ptgpu_set_record_overlap", "ptgpu_set_bvh_builder", "ptgpu_bvh_built_on_device",
     "ptgpu_set_final_training",
 ]
@@ -158,6 +158,8 @@ def load_gpu() -> C.CDLL:
         lib.ptgpu_guided_probe.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_uint32, C.c_uint64, C.c_void_p]
         lib.ptgpu_guided_record_batch.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_uint32]
         lib.ptgpu_guided_refine.argtypes = [C.c_void_p]
+        lib.ptgpu_guided_capture_records.argtypes = [C.c_void_p, C.c_int]
+        lib.ptgpu_guided_captured_records.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
         lib.ptgpu_trace_batch.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_uint32, C.c_void_p]
         lib.ptgpu_trace_batch_noalloc.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_uint32, C.c_void_p]
         lib.ptgpu_occluded_batch.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_uint32, C.POINTER(C.c_uint8)]
@@ -506,6 +508,18 @@ class Context:
 
     def guided_refine(self):
         self._check(self.lib.ptgpu_guided_refine(self.handle))
+
+    def guided_capture_records(self, enabled: bool):
+        self._check(self.lib.ptgpu_guided_capture_records(self.handle, 1 if enabled else 0))
+
+    def guided_captured_records(self) -> np.ndarray:
+        """-> (n, 14) uint32 words per record of the last wave traced with capture on (see include/ptgpu.h)."""
+        n = C.c_uint64()
+        self._check(self.lib.ptgpu_guided_captured_records(self.handle, None, 0, C.byref(n)))
+        out = np.zeros((n.value, 14), dtype=np.uint32)
+        if n.value:
+            self._check(self.lib.ptgpu_guided_captured_records(self.handle, out.ctypes.data_as(C.c_void_p), n.value, C.byref(n)))
+        return out
 
     def guided_end(self, host_film: bool = True):
         film = np.zeros((self.cam.resy, self.cam.resx, 3), dtype=np.float64) if host_film else None

@@ -1001,6 +1001,7 @@ struct RecordQueue {
     float4* q1;       // wi.xyz, u0
     float2* q2;       // u1, u2
     uint32_t* count;  // records per chunk
+    uint4* who;       // parity hook only (ptgpu_guided_capture_records), else NULL: {path id, vertex row, pixel, -} per record
 };
 
 __global__ __launch_bounds__(kBlock, PT_SCAN_WAVES) void k_guide_scan(SceneDev sc, RenderParams rp, GuidedParams gp, RecordQueue rq, uint32_t n_paths) {
@@ -1078,6 +1079,7 @@ __global__ __launch_bounds__(kBlock, PT_SCAN_WAVES) void k_guide_scan(SceneDev s
                     rq.q0[slot] = make_float4(pp.x, pp.y, pp.z, radiance);
                     rq.q1[slot] = make_float4(wi.x, wi.y, wi.z, u0);
                     rq.q2[slot] = make_float2(u1, u2);
+                    if (rq.who) rq.who[slot] = make_uint4(pid, v, rp4.z, 0u);
                 }
             }
         }

@@ -178,6 +178,8 @@ struct ptgpu_ctx {
     bool has_passthrough = false;      // the resident scene has surfaces without a material (material_index < 0): walks may take more rounds than max_depth
     bool train_last_wave = true;       // ptgpu_set_final_training
     bool direct_splat = false;         // PTGPU_DIRECT_SPLAT, sampled at the start of a wave
+    bool capture_records = false;      // ptgpu_guided_capture_records (parity hook)
+    std::vector<uint32_t> captured;    // 14 words per record of the last wave traced with the hook on
     bool record_overlap = getenv("PTGPU_NO_OVERLAP") == nullptr;  // guided: record pass on the second stream (ptgpu_set_record_overlap)
     bool film_ready = false;           // d_film_packed holds the film of the last completed render
     unsigned char* scratch = nullptr;  // device address of `scratch` on this context's GPU (hipGetSymbolAddress)

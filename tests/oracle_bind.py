@@ -45,6 +45,9 @@ def load():
         lib.orc_sdtree_probe.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_uint32, C.c_uint64, C.c_void_p]
         lib.orc_sdtree_record.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_uint32]
         lib.orc_sdtree_new_iteration.argtypes = [C.c_void_p, C.c_uint32]
+        lib.orc_sdtree_log_records.argtypes = [C.c_void_p, C.c_int]
+        lib.orc_sdtree_logged_records.restype = C.c_uint64
+        lib.orc_sdtree_logged_records.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
         lib.orc_guided_wave.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(pt.CameraDesc), C.POINTER(pt.IntegratorDesc), C.c_uint32, C.c_uint64, C.c_uint32,
                                         C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
         _lib = lib
@@ -177,6 +180,18 @@ class OracleSdTree:
 
     def new_iteration(self, iteration: int):
         self.lib.orc_sdtree_new_iteration(self.handle, iteration)
+
+    def log_records(self, enabled: bool):
+        """Keep Guider::add's arguments (mod.rs:106-115) of the waves traced from now on (cleared by every call)."""
+        self.lib.orc_sdtree_log_records(self.handle, 1 if enabled else 0)
+
+    def logged_records(self) -> np.ndarray:
+        """-> (n, 14) uint32 words per record, the layout of ptgpu_guided_captured_records."""
+        n = self.lib.orc_sdtree_logged_records(self.handle, None, 0)
+        out = np.zeros((n, 14), dtype=np.uint32)
+        if n:
+            self.lib.orc_sdtree_logged_records(self.handle, out.ctypes.data_as(C.c_void_p), n)
+        return out
 
     def wave(self, oscene: "OracleScene", cam, integrator, iteration, first_pass, n_passes, n_threads=0):
         """-> (film sums of this wave (H,W,3), stats dict)"""
