@@ -315,9 +315,11 @@ def main() -> int:
                "sample": f"{scene_name} {resx}x{resy} @ {cpu_spp} spp, {integrator}, max_depth {max_depth} ({dt:.1f} s; C++ restatement of the reference, "
                          "the Rust reference cannot be built in this image; parity with the Rust binary is pinned by the 8 furnace fixtures only)"}
 
-    # ---- image check next to the throughput number (BASELINE metric: "relMSE vs CPU reference"): the Cornell box at 64 x 64,
-    # GPU at 1 024 spp against the CPU oracle's converged image (16 384 spp, tests/golden/converged_cornell_64.npz, written
-    # by tests/golden/make_converged.py); the yardstick beside it is the oracle's own relMSE at the same 1 024 spp.
+    # ---- image check next to the throughput number (BASELINE metric: "relMSE vs CPU reference"): the Cornell box at 64 x 64
+    # against the CPU oracle's converged image (16 384 spp, guided 16 383: tests/golden/converged_cornell_64.npz, written by
+    # tests/golden/make_converged.py). path / lightpath draw the oracle's very samples, so at the reference's sample count
+    # they must render the reference's image; guided runs free and is compared at 65 535 spp, where what is left is the
+    # reference image's own noise. The 4 x 4 block figure is the one fireflies do not decide (tests/test_golden.py).
     relmse = None
     gold = REPO / "tests" / "golden" / "converged_cornell_64.npz"
     key = {"guided": "guided", "path": "path", "lightpath": "lightpath"}.get(args.workload)
@@ -325,12 +327,18 @@ def main() -> int:
         g = np.load(gold)
         small = pt.LoadedScene(scene_name, resx=64, resy=64, max_depth=16, integrator=integrator)
         ctx.load(small)
-        gf, gs, _ = ctx.render(integ, int(g[f"{key}_spp"]))
-        ref = g[f"{key}_ref"]
-        relmse = {"gpu_vs_converged_oracle": round(float(np.mean((gf * gs - ref) ** 2 / (ref ** 2 + 1e-2))), 5),
-                  "oracle_vs_converged_oracle": round(float(g[f"{key}_oracle_relmse"]), 5), "spp": int(g[f"{key}_spp"]),
-                  "reference_spp": int(g[f"{key}_ref_spp"]), "res": "64x64", "max_depth": 16,
-                  "note": "relMSE = mean((I-R)^2 / (R^2 + 1e-2)) on the linear film; parity with the Rust binary itself is unpinned beyond the furnace fixtures"}
+        ref, ref_spp = g[f"{key}_ref"], int(g[f"{key}_ref_spp"])
+        img_spp = 65535 if guided else ref_spp
+        gf, gs, _ = ctx.render(integ, img_spp)
+        img = gf * gs
+        blk = lambda x: x.reshape(16, 4, 16, 4, 3).mean(axis=(1, 3))  # noqa: E731
+        rel = lambda a, b: float(np.mean((a - b) ** 2 / (b ** 2 + 1e-2)))  # noqa: E731
+        relmse = {"gpu_vs_converged_oracle": float(f"{rel(img, ref):.4g}"), "gpu_vs_converged_oracle_4x4_blocks": float(f"{rel(blk(img), blk(ref)):.4g}"),
+                  "spp": img_spp, "reference_spp": ref_spp, "res": "64x64", "max_depth": 16,
+                  "stated_bound": {"guided": "relMSE < 0.03, 4x4 blocks < 0.003 (the 16 383-spp reference's own noise)", "path": "relMSE < 1e-4 (same samples: the same image)",
+                                   "lightpath": "relMSE < 1e-4 (same samples: the same image)"}[key],
+                  "note": "relMSE = mean((I-R)^2 / (R^2 + 1e-2)) on the linear film; convergence with N is asserted in tests/test_golden.py; "
+                          "parity with the Rust binary itself is unpinned beyond the furnace fixtures"}
         ctx.load(sc)
 
     out = {
