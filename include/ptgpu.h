@@ -6,7 +6,7 @@
  * The reference has no FFI; these entry points are what an `extern "C"` block in a thin Rust FFI crate
  * would bind (see INTEGRATION.md for the Rust side). Plain pointers and sizes only; the caller owns every
  * host buffer; the library copies what it needs during the call. All functions return 0 on success or a
- * negative PTGPU_E_* code and never throw/abort across the ABI; ptgpu_last_error() gives the message.
+ * negative PTGPU_E_* code (or the warning PTGPU_W_NONFINITE, 1) and never throw/abort across the ABI; ptgpu_last_error() gives the message.
  * One context = one GPU; a context is not re-entrant (one call at a time), calls block until done.
  */
 #ifndef PTGPU_H
@@ -23,6 +23,10 @@ extern "C" {
 #define PTGPU_E_DEVICE (-2)   /* HIP runtime error (no GPU, out of memory, launch failure) */
 #define PTGPU_E_STATE (-3)    /* call order (e.g. render before scene_create / camera_set) */
 #define PTGPU_E_LIMIT (-4)    /* a documented limit was exceeded (e.g. DTree > 65535 nodes) */
+#define PTGPU_W_NONFINITE 1    /* the one positive code: the render is COMPLETE (film, scale and stats delivered), but `path` met
+                                * samples whose radiance was not finite and left them out — where the reference asserts
+                                * (path_tracer.rs:46; the MIS weight of a grazing light sample is inf / inf about once in 10^6
+                                * samples of the furnace fixtures). ptgpu_stats::nonfinite_samples says how many. */
 
 typedef struct ptgpu_ctx ptgpu_ctx;
 
@@ -96,6 +100,9 @@ typedef struct ptgpu_stats {
     double shade_ms;
     uint64_t stree_nodes;    /* guided: final spatial tree size */
     uint64_t dtree_nodes;    /* guided: total directional nodes over leaves */
+    uint64_t nonfinite_samples; /* samples left out of the film because their radiance was not finite: a `path` render
+                                 * returns PTGPU_W_NONFINITE when this is not 0 (the reference asserts); lightpath / guided,
+                                 * whose reference loops do not check, return PTGPU_OK and report it here */
 } ptgpu_stats;
 
 typedef struct ptgpu_hit {

@@ -125,6 +125,8 @@ int orc_occluded_batch(orc_scene* s, const float* from, const float* to, uint32_
 // Integrator::render + Film::create_pixels(1.0) + film_scale. n_threads <= 0 -> hardware_concurrency.
 // stats_out[8]: samples, extend_rays, shadow_rays, segments, nodes, tris, stree_nodes, dtree_nodes.
 // max_waves: guided only, stop after that many waves (0 = all).
+// Returns 2 (film and stats filled, the offending samples left out) when a `path` render met a sample whose radiance is
+// not finite: PathIntegrator::render asserts there (path_tracer.rs:46); the other two integrators' loops do not check.
 int orc_render(orc_scene* s, const ptgpu_camera_desc* cam, const ptgpu_integrator_desc* integ, uint32_t spp, uint32_t shard_index,
                uint32_t shard_count, int n_threads, uint32_t max_waves, double* film_out, double* film_scale_out, uint64_t* stats_out) {
     if (!s || !cam || !integ || shard_count == 0) return -1;
@@ -145,6 +147,7 @@ int orc_render(orc_scene* s, const ptgpu_camera_desc* cam, const ptgpu_integrato
     RayStats st;
     GuidedReport rep;
     TraversalCounters tc;
+    const uint64_t nonfinite_before = nonfinite_samples().load();
     // traversal counters are not thread safe: only collect them single-threaded
     s->scene.counters = (n_threads == 1) ? &tc : nullptr;
     switch (it.kind) {
@@ -168,6 +171,7 @@ int orc_render(orc_scene* s, const ptgpu_camera_desc* cam, const ptgpu_integrato
         stats_out[6] = rep.stree_nodes;
         stats_out[7] = rep.dtree_nodes_total;
     }
+    if (it.kind == IntegratorKind::Path && nonfinite_samples().load() != nonfinite_before) return 2;
     return 0;
 }
 

@@ -23,7 +23,16 @@ REPO = _PKG.parent
 
 
 class PtError(RuntimeError):
-    pass
+    """A negative PTGPU_E_* / PTHOST_E_* return code (`code`)."""
+    code = 0
+
+
+class NonFiniteSampleWarning(RuntimeWarning):
+    """PTGPU_W_NONFINITE: a `path` render met samples whose radiance is not finite (the reference asserts there,
+    path_tracer.rs:46); the render is complete without them and stats["nonfinite_samples"] counts them."""
+
+
+W_NONFINITE = 1
 
 
 # ----------------------------------------------------------------------------- C structs (include/ptgpu.h)
@@ -57,7 +66,7 @@ class IntegratorDesc(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("samples", C.c_uint64), ("extend_rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("segments", C.c_uint64),
                 ("kernel_launches", C.c_uint64), ("render_ms", C.c_double), ("extend_ms", C.c_double), ("shade_ms", C.c_double),
-                ("stree_nodes", C.c_uint64), ("dtree_nodes", C.c_uint64)]
+                ("stree_nodes", C.c_uint64), ("dtree_nodes", C.c_uint64), ("nonfinite_samples", C.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -301,8 +310,13 @@ class Context:
         self.cam = None
 
     def _check(self, rc):
-        if rc != 0:
-            raise PtError(f"ptgpu error {rc}: {self.lib.ptgpu_last_error().decode()}")
+        if rc == W_NONFINITE:
+            import warnings
+            warnings.warn(self.lib.ptgpu_last_error().decode(), NonFiniteSampleWarning, stacklevel=3)
+        elif rc != 0:
+            e = PtError(f"ptgpu error {rc}: {self.lib.ptgpu_last_error().decode()}")
+            e.code = rc
+            raise e
 
     def close(self):
         if getattr(self, "handle", None):

@@ -178,6 +178,8 @@ struct ptgpu_ctx {
     bool has_passthrough = false;      // the resident scene has surfaces without a material (material_index < 0): walks may take more rounds than max_depth
     bool train_last_wave = true;       // ptgpu_set_final_training
     bool direct_splat = false;         // PTGPU_DIRECT_SPLAT, sampled at the start of a wave
+    uint32_t nonfinite_seen = 0;       // kGuardNonFinite as of the last film download
+    uint64_t nonfinite_last = 0;       // ... and how many of them the render that film belongs to dropped (ptgpu_stats::nonfinite_samples)
     bool capture_records = false;      // ptgpu_guided_capture_records (parity hook)
     std::vector<uint32_t> captured;    // 14 words per record of the last wave traced with the hook on
     bool record_overlap = getenv("PTGPU_NO_OVERLAP") == nullptr;  // guided: record pass on the second stream (ptgpu_set_record_overlap)
@@ -1109,7 +1111,11 @@ int download_film(ptgpu_ctx* c, double* film_out) {
     hipLaunchKernelGGL(k_pack_film, dim3((3 * npix + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, c->d_film.p, c->d_film_packed.p, npix, c->film_copies);
     HIP_TRY(hipGetLastError());
     if (film_out) HIP_TRY(hipMemcpyAsync(film_out, c->d_film_packed.p, 3 * (size_t)npix * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    uint32_t nonfinite_now = 0;
+    HIP_TRY(hipMemcpyAsync(&nonfinite_now, c->d_guards.p + kGuardNonFinite, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    c->nonfinite_last = nonfinite_now - c->nonfinite_seen;  // (u32 wrap-around safe)
+    c->nonfinite_seen = nonfinite_now;
     c->film_ready = true;
     return PTGPU_OK;
 }
@@ -1151,7 +1157,12 @@ int ptgpu_render_shard(ptgpu_ctx* c, const ptgpu_integrator_desc* integ, uint32_
         stats->extend_ms = c->stage_ms[PTGPU_STAGE_EXTEND] + c->stage_ms[PTGPU_STAGE_OCCLUDE];
         stats->shade_ms = c->stage_ms[PTGPU_STAGE_SHADE];
         stats->kernel_launches = c->launches;
+        stats->nonfinite_samples = c->nonfinite_last;
     }
+    // PathIntegrator::render asserts that every sample is finite (path_tracer.rs:46) and LightPathIntegrator does not: a
+    // `path` render that met one says so (the render is complete: film and stats are delivered, without those samples).
+    if (c->nonfinite_last != 0 && integ->kind == PTGPU_INTEGRATOR_PATH)
+        return fail(PTGPU_W_NONFINITE, "render: " + std::to_string(c->nonfinite_last) + " sample(s) with non-finite radiance (the reference asserts, path_tracer.rs:46); they are left out of the film");
     return PTGPU_OK;
 }
 

@@ -65,7 +65,8 @@ int main(int argc, char** argv) {
         const auto t0 = std::chrono::steady_clock::now();
         const int r = ptgpu_render(ctx, integ, pthost_spp(sc), film.data(), &scale, &st);
         const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-        if (r != PTGPU_OK) {
+        if (r == PTGPU_W_NONFINITE) fprintf(stderr, "%s: warning: %s\n", name.c_str(), ptgpu_last_error());  // (the reference would have panicked)
+        if (r < 0) {
             fprintf(stderr, "%s: render: %s\n", name.c_str(), ptgpu_last_error());
             rc = 1;
         } else {

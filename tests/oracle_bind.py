@@ -58,6 +58,10 @@ def fptr(a):
     return a.ctypes.data_as(C.POINTER(C.c_float))
 
 
+class NonFiniteSample(RuntimeWarning):
+    """PathIntegrator::render's assert (path_tracer.rs:46), as the oracle reports it."""
+
+
 class OracleScene:
     def __init__(self, scene):
         self.lib = load()
@@ -113,7 +117,10 @@ class OracleScene:
         st = (C.c_uint64 * 8)()
         rc = self.lib.orc_render(self.handle, C.byref(cam), C.byref(integ), spp, shard_index, shard_count, n_threads, max_waves,
                                  film.ctypes.data_as(C.POINTER(C.c_double)), C.byref(scale), st)
-        if rc != 0:
+        if rc == 2:   # complete, but where the reference would have panicked: say so, like the product's PTGPU_W_NONFINITE
+            import warnings
+            warnings.warn("orc_render: a sample's radiance is not finite (path_tracer.rs:46 asserts); left out of the film", NonFiniteSample, stacklevel=2)
+        elif rc != 0:
             raise RuntimeError("orc_render failed")
         keys = ["samples", "extend_rays", "shadow_rays", "segments", "nodes", "tris", "stree_nodes", "dtree_nodes"]
         return film, scale.value, dict(zip(keys, list(st)))
