@@ -8,18 +8,26 @@ HIPFLAGS = -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -munsafe-fp-at
 CSRC = $(PKG)/csrc
 GPU_DEPS = $(wildcard $(CSRC)/*.h $(CSRC)/*.inc) include/ptgpu.h
 
-all: $(LIB)/libptgpu.so $(LIB)/libpthost.so $(LIB)/pt $(LIB)/calib_fetch oracle
+all: $(LIB)/libptgpu.so $(LIB)/libpthost.so $(LIB)/pt $(LIB)/calib_fetch $(LIB)/rgb2spec_opt oracle
 
 $(LIB)/libptgpu.so: $(CSRC)/ptgpu.hip $(CSRC)/bvh_build.cpp $(CSRC)/sdtree_host.cpp $(GPU_DEPS)
 	mkdir -p $(LIB)
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/ptgpu.hip $(CSRC)/bvh_build.cpp $(CSRC)/sdtree_host.cpp
 
-$(LIB)/libpthost.so: $(PKG)/host/pthost.cpp include/pthost.h include/ptgpu.h $(CSRC)/cie_data.inc
+$(LIB)/libpthost.so: $(PKG)/host/pthost.cpp $(PKG)/host/rgb2spec_fit.h include/pthost.h include/ptgpu.h $(CSRC)/cie_data.inc
 	mkdir -p $(LIB)
 	$(CXX) -O2 -std=c++17 -fPIC -ffp-contract=off -Wall -shared -o $@ $(PKG)/host/pthost.cpp -ldl -lz
 
 $(LIB)/pt: $(PKG)/host/pt_main.cpp $(LIB)/libpthost.so $(LIB)/libptgpu.so
 	$(CXX) -O2 -std=c++17 -Wall -o $@ $(PKG)/host/pt_main.cpp -L$(LIB) -lpthost -lptgpu -Wl,-rpath,'$$ORIGIN'
+
+# Regenerates the RGB-to-spectrum coefficient table the reference embeds (srgb.coeffs, missing from its tree) and the excerpt
+# shipped in $(PKG)/data (tools/rgb2spec_opt.cpp; build container only): `make rgb2spec-table`
+$(LIB)/rgb2spec_opt: tools/rgb2spec_opt.cpp $(PKG)/host/rgb2spec_fit.h $(CSRC)/cie_data.inc
+	mkdir -p $(LIB)
+	$(CXX) -O2 -std=c++17 -pthread -o $@ tools/rgb2spec_opt.cpp
+rgb2spec-table: $(LIB)/rgb2spec_opt
+	$(LIB)/rgb2spec_opt --full $(LIB)/srgb.coeffs --slab $(PKG)/data/srgb_z05.coeffs
 
 # FETCH_SIZE calibration micro-benchmark (tools/gpu_calib_fetch.sh); a measuring tool, not part of the product
 $(LIB)/calib_fetch: tools/calib_fetch.hip
@@ -32,4 +40,4 @@ oracle:
 clean:
 	rm -rf $(LIB) oracle/_build
 
-.PHONY: all oracle clean
+.PHONY: all oracle clean rgb2spec-table

@@ -104,7 +104,8 @@ PTGPU_SYMBOLS = [
 ]
 PTHOST_SYMBOLS = [
     "pthost_last_error", "pthost_scene_load", "pthost_scene_free", "pthost_scene_desc", "pthost_camera_desc",
-    "pthost_integrator_desc", "pthost_spp", "pthost_output_name", "pthost_rgb_to_spectrum", "pthost_save_image", "pthost_save_pfm", "pthost_save_image_film",
+    "pthost_integrator_desc", "pthost_spp", "pthost_output_name", "pthost_rgb_to_spectrum", "pthost_rgb_to_spectrum_fit", "pthost_rgb2spec_use",
+    "pthost_rgb2spec_fetch", "pthost_rgb2spec_find_interval", "pthost_save_image", "pthost_save_pfm", "pthost_save_image_film",
 ]
 
 _gpu = None
@@ -133,6 +134,10 @@ def load_host() -> C.CDLL:
         lib.pthost_output_name.restype = C.c_char_p
         lib.pthost_output_name.argtypes = [C.c_void_p]
         lib.pthost_rgb_to_spectrum.argtypes = [C.POINTER(C.c_float), C.POINTER(Spectrum)]
+        lib.pthost_rgb_to_spectrum_fit.argtypes = [C.POINTER(C.c_float), C.POINTER(Spectrum)]
+        lib.pthost_rgb2spec_use.argtypes = [C.c_char_p]
+        lib.pthost_rgb2spec_fetch.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        lib.pthost_rgb2spec_find_interval.argtypes = [C.POINTER(C.c_float), C.c_uint32, C.c_float]
         lib.pthost_save_image.argtypes = [C.POINTER(C.c_double), C.c_uint32, C.c_uint32, C.c_double, C.c_int, C.c_char_p, C.c_char_p]
         lib.pthost_save_image_film.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_uint32, C.c_uint32, C.c_double, C.c_char_p, C.c_char_p]
         lib.pthost_save_pfm.argtypes = [C.POINTER(C.c_double), C.c_uint32, C.c_uint32, C.c_double, C.c_char_p]
@@ -271,13 +276,36 @@ class LoadedScene:
             pass
 
 
-def rgb_to_spectrum(rgb) -> Spectrum:
+def rgb_to_spectrum(rgb, fit: bool = False) -> Spectrum:
+    """TristimulusSpectrum::new: table lookup (rgb2spec::fetch_coeffs); fit=True: the direct fit of that colour instead."""
     lib = load_host()
     a = (C.c_float * 3)(*[float(v) for v in rgb])
     out = Spectrum()
-    if lib.pthost_rgb_to_spectrum(a, C.byref(out)) != 0:
+    if (lib.pthost_rgb_to_spectrum_fit if fit else lib.pthost_rgb_to_spectrum)(a, C.byref(out)) != 0:
         raise PtError(lib.pthost_last_error().decode())
     return out
+
+
+def rgb2spec_use(path=None):
+    """Use the coefficient table at `path` (the reference's srgb.coeffs layout or this repo's excerpt); None: the default."""
+    lib = load_host()
+    if lib.pthost_rgb2spec_use(str(path).encode() if path is not None else None) != 0:
+        raise PtError(lib.pthost_last_error().decode())
+
+
+def rgb2spec_fetch(rgb) -> np.ndarray:
+    """rgb2spec::fetch_coeffs (rgb2spec.rs:8-54) on the table in use."""
+    lib = load_host()
+    a = (C.c_float * 3)(*[float(v) for v in rgb])
+    out = (C.c_float * 3)()
+    if lib.pthost_rgb2spec_fetch(a, out) != 0:
+        raise PtError("rgb2spec_fetch: no table, or the colour is outside the shipped slices")
+    return np.array(list(out), dtype=np.float32)
+
+
+def rgb2spec_find_interval(values, x) -> int:
+    v = np.ascontiguousarray(values, dtype=np.float32)
+    return load_host().pthost_rgb2spec_find_interval(v.ctypes.data_as(C.POINTER(C.c_float)), len(v), C.c_float(x))
 
 
 def make_camera(world_to_camera, fov_deg, resx, resy) -> CameraDesc:

@@ -19,7 +19,7 @@ REPO = Path(__file__).resolve().parent.parent
 # ------------------------------------------------------------------ ABI surface
 def test_ptgpu_exports_every_declared_symbol():
     header = (REPO / "include" / "ptgpu.h").read_text()
-    declared = set(re.findall(r"^(?:int|void|const char\*)\s+(ptgpu_[a-z_]+)\s*\(", header, re.M))
+    declared = set(re.findall(r"^(?:int|void|const char\*)\s+(ptgpu_[a-z0-9_]+)\s*\(", header, re.M))
     assert declared == set(pt.PTGPU_SYMBOLS), declared ^ set(pt.PTGPU_SYMBOLS)
     lib = C.CDLL(str(pt.LIB_DIR / "libptgpu.so"))
     for name in sorted(declared):
@@ -28,7 +28,7 @@ def test_ptgpu_exports_every_declared_symbol():
 
 def test_pthost_exports_every_declared_symbol():
     header = (REPO / "include" / "pthost.h").read_text()
-    declared = set(re.findall(r"^(?:int|void|uint32_t|const [a-z_]+\*|pthost_scene\*)\s+(pthost_[a-z_]+)\s*\(", header, re.M))
+    declared = set(re.findall(r"^(?:int|void|uint32_t|const [a-z_]+\*|pthost_scene\*)\s+(pthost_[a-z0-9_]+)\s*\(", header, re.M))
     assert declared == set(pt.PTHOST_SYMBOLS), declared ^ set(pt.PTHOST_SYMBOLS)
     lib = pt.load_host()
     for name in sorted(declared):
