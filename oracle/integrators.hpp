@@ -442,12 +442,15 @@ struct GuidedReport {
 
 // The sample passes [first_index, first_index + wave_size) of one wave (mod.rs:84-118): every pass visits every pixel
 // once, tile-parallel, records each path back to front into the collectors and adds it to the film.
+// shard_index / shard_count: only the tiles t of pass i with (t + i) % shard_count == shard_index are traced (the product's
+// multi-GPU rule, pt_guided.h: k_raygen_guided; the reference itself is one process: 0 / 1).
 inline void guided_wave_passes(const Scene& scene, const Camera& cam, const IntegratorDesc& it, Guider& guider, Film& film, size_t first_index,
-                               size_t wave_size, int n_threads, RayStats* st) {
+                               size_t wave_size, int n_threads, RayStats* st, size_t shard_index = 0, size_t shard_count = 1) {
     auto tiles = create_tiles(film.w, film.h);
     for (size_t k = 0; k < wave_size; k++) {
         size_t i = first_index + k;
-        parallel_tiles(tiles, n_threads, [&](const Tile& tile, size_t) {
+        parallel_tiles(tiles, n_threads, [&](const Tile& tile, size_t tile_index) {
+            if ((tile_index + i) % shard_count != shard_index) return;
             std::vector<PathVertex> path;
             Sampler sampler;
             for (size_t oy = 0; oy < tile.size[1]; oy++)

@@ -486,9 +486,10 @@ void orc_sdtree_new_iteration(orc_sdtree* t, uint32_t iteration) {  // Guider::n
 }
 // One wave of PathGuidingIntegrator::render on this tree: passes [first_pass, first_pass + n_passes) with Guider::iteration
 // = `iteration`; the film holds this wave only (film.clear(), mod.rs:80). stats_out[4]: samples, extend, shadow, segments.
+// shard_index / shard_count: this rank's (pass, tile) pairs of a multi-GPU job (guided_wave_passes); 0 / 1 = all of them.
 int orc_guided_wave(orc_scene* s, orc_sdtree* t, const ptgpu_camera_desc* cam, const ptgpu_integrator_desc* integ, uint32_t iteration, uint64_t first_pass,
-                    uint32_t n_passes, int n_threads, double* film_out, uint64_t* stats_out) {
-    if (!s || !t || !cam || !integ) return -1;
+                    uint32_t n_passes, int n_threads, uint32_t shard_index, uint32_t shard_count, double* film_out, uint64_t* stats_out) {
+    if (!s || !t || !cam || !integ || shard_count == 0 || shard_index >= shard_count) return -1;
     if (n_threads <= 0) n_threads = (int)std::thread::hardware_concurrency();
     if (n_threads <= 0) n_threads = 1;
     Camera camera;
@@ -506,11 +507,11 @@ int orc_guided_wave(orc_scene* s, orc_sdtree* t, const ptgpu_camera_desc* cam, c
     RayStats st;
     t->guider.iteration = iteration;
     t->guider.has_started = true;
-    guided_wave_passes(s->scene, camera, it, t->guider, film, (size_t)first_pass, n_passes, n_threads, &st);
+    guided_wave_passes(s->scene, camera, it, t->guider, film, (size_t)first_pass, n_passes, n_threads, &st, shard_index, shard_count);
     if (film_out)
         for (size_t i = 0; i < film.pixels.size(); i++) film_out[i] = film.pixels[i] + film.splats[i];
     if (stats_out) {
-        stats_out[0] = (uint64_t)n_passes * cam->resx * cam->resy;
+        stats_out[0] = (uint64_t)n_passes * cam->resx * cam->resy;  // (of all shards together)
         stats_out[1] = st.extend_rays.load();
         stats_out[2] = st.shadow_rays.load();
         stats_out[3] = st.segments.load();

@@ -62,19 +62,31 @@ def device_stats_tensor(torch, dev):
     return lambda ptr, count, typestr="<f4": torch.as_tensor(DeviceArray(ptr, count, typestr), device=dev)
 
 
+def _accepts_typestr(fn) -> bool:
+    import inspect
+    try:
+        params = list(inspect.signature(fn).parameters.values())
+    except (TypeError, ValueError):
+        return False
+    return len(params) >= 3 or any(p.kind == p.VAR_POSITIONAL for p in params)
+
+
 def render_sharded(ctx, integ, spp, rank, world, guided, dist=None, wrap_stats=None, film_buf=None, sync=lambda: None, collectives=None):
     """One render of the whole job on this rank's shard. Returns (film sums [complete on rank 0], film_scale, stats).
 
     ctx       : object with render(integ, spp, rank, world) and guided_{begin,wave,stats,end} (path_tracer_amd.Context)
     dist      : torch.distributed (initialised) when world > 1
-    wrap_stats: (ptr_or_buffer, count) -> tensor aliasing the statistics buffer
+    wrap_stats: (ptr_or_buffer, count[, typestr]) -> tensor aliasing a buffer of the context: the float32 statistics by
+                default, the float64 film with typestr "<f8" (device_stats_tensor). A callable without the third
+                parameter (or None, for path / lightpath) sends the film through the host copy and `film_buf` instead
     film_buf  : preallocated float64 tensor (H, W, 3) on the collective's device
     sync      : waits for the collective's stream (torch.cuda.synchronize on GPU)
     collectives: run the collectives even when world == 1 (rehearsal of the RCCL path on a one-GPU box); default world > 1
     """
     if collectives is None:
         collectives = world > 1
-    on_device = collectives and hasattr(ctx, "film_device")  # reduce straight from the library's film buffer
+    # reduce straight from the library's film buffer where the caller's wrapper can alias it
+    on_device = collectives and hasattr(ctx, "film_device") and wrap_stats is not None and _accepts_typestr(wrap_stats)
     if guided:
         n_waves = ctx.guided_begin(integ, spp, rank, world)
         for w in range(n_waves):

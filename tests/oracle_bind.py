@@ -49,7 +49,7 @@ def load():
         lib.orc_sdtree_logged_records.restype = C.c_uint64
         lib.orc_sdtree_logged_records.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
         lib.orc_guided_wave.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(pt.CameraDesc), C.POINTER(pt.IntegratorDesc), C.c_uint32, C.c_uint64, C.c_uint32,
-                                        C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+                                        C.c_int, C.c_uint32, C.c_uint32, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
         _lib = lib
     return _lib
 
@@ -200,13 +200,13 @@ class OracleSdTree:
             self.lib.orc_sdtree_logged_records(self.handle, out.ctypes.data_as(C.c_void_p), n)
         return out
 
-    def wave(self, oscene: "OracleScene", cam, integrator, iteration, first_pass, n_passes, n_threads=0):
-        """-> (film sums of this wave (H,W,3), stats dict)"""
+    def wave(self, oscene: "OracleScene", cam, integrator, iteration, first_pass, n_passes, n_threads=0, shard_index=0, shard_count=1):
+        """-> (film sums of this wave (H,W,3), stats dict); shard_*: this rank's (pass, tile) pairs of a multi-GPU job"""
         cam = pt.CameraDesc.from_buffer_copy(cam)
         integ = pt.IntegratorDesc.from_buffer_copy(integrator)
         film = np.zeros((cam.resy, cam.resx, 3), dtype=np.float64)
         st = (C.c_uint64 * 4)()
-        rc = self.lib.orc_guided_wave(oscene.handle, self.handle, C.byref(cam), C.byref(integ), iteration, C.c_uint64(first_pass), n_passes, n_threads,
+        rc = self.lib.orc_guided_wave(oscene.handle, self.handle, C.byref(cam), C.byref(integ), iteration, C.c_uint64(first_pass), n_passes, n_threads, shard_index, shard_count,
                                       film.ctypes.data_as(C.POINTER(C.c_double)), st)
         if rc != 0:
             raise RuntimeError("orc_guided_wave failed")

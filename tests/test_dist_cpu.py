@@ -1,9 +1,13 @@
-"""world_size-2 rehearsal of the multi-GPU driver (path-tracer_amd/multi_gpu.py) on CPU with the gloo backend.
+"""world_size-2 and world_size-8 rehearsals of the multi-GPU driver (path-tracer_amd/multi_gpu.py) on CPU with the gloo backend.
 
 What runs here is the SAME driver function bench.py uses with RCCL; the renderer behind it is a stand-in:
   * path / lightpath: the oracle rendering its sample-index shard — the reduced film must equal the unsharded render;
-  * guided: a stub context that deals (pass, tile) pairs by the library's rule and deposits one unit per pair into a
-    statistics buffer — after the per-wave all-reduce every rank must see every pair exactly once.
+  * guided, protocol: a stub context that deals (pass, tile) pairs by the library's rule and deposits one unit per pair into
+    a statistics buffer — after the per-wave all-reduce every rank must see every pair exactly once;
+  * guided, end to end: the ORACLE behind the same four calls — every rank traces its (pass, tile) pairs of a wave into its
+    own collector, the collector sums and leaf weights are all-reduced as one flat buffer, every rank refines the same tree
+    from the sums — against the oracle's single-process render of the same job ("all-reduced tree sums equal to
+    a serial sum within f32 reassociation tolerance", "1-GPU vs N-GPU image").
 No GPU and no libptgpu compute is involved (the C ABI has no CPU path by design).
 """
 import os
@@ -20,7 +24,7 @@ REPO = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(REPO))
 sys.path.insert(0, str(REPO / "tests"))
 
-WORLD = 2
+WORLDS = (2, 8)
 
 
 def _free_port():
@@ -73,7 +77,49 @@ class StubGuidedContext:
         return film, 1.0, {"samples": int(self.stats.sum())}
 
 
-def _worker(rank, port, q):
+class OracleGuidedContext:
+    """guided_{begin,wave,stats,end} of path_tracer_amd.Context, served by the oracle's Guider: the statistics buffer is the
+    product's (collector sums, 4 per quadtree node, then one weight per spatial leaf: ptgpu_guided_stats), the tree of the
+    next wave is refined from whatever the driver left in it."""
+
+    def __init__(self, scene, cam, thr):
+        import oracle_bind as ob
+        self.ob, self.o, self.cam, self.thr = ob, ob.OracleScene(scene), cam, thr
+
+    def guided_begin(self, integ, spp, rank, world):
+        import ctypes as C
+        n, buf = C.c_uint32(), (C.c_uint32 * 64)()
+        self.ob.load().orc_wave_sample_counts(spp, C.byref(n), buf, 64)
+        self.waves = [int(buf[i]) for i in range(n.value)]
+        self.integ, self.rank, self.world, self.first = integ, rank, world, 0
+        self.tree = self.ob.OracleSdTree.fresh(self.o, self.thr)
+        self.nodes = []
+        return len(self.waves)
+
+    def guided_wave(self, w):
+        if w > 0:   # STree::new_iteration from the (all-reduced) statistics the driver left in self.stats
+            t = dict(self.flat)
+            n = t["c_rad"].size
+            t["c_rad"] = self.stats[:n].numpy().reshape(-1, 4).copy()
+            t["c_weight"] = self.stats[n:].numpy().copy()
+            self.summed = (t["c_rad"], t["c_weight"])
+            self.tree.close()
+            self.tree = self.ob.OracleSdTree.from_arrays(t, self.thr)
+            self.tree.new_iteration(w - 1)
+        self.film, _ = self.tree.wave(self.o, self.cam, self.integ, w, self.first, self.waves[w], n_threads=1, shard_index=self.rank, shard_count=self.world)
+        self.first += self.waves[w]
+        self.flat = self.tree.export()
+        self.nodes.append((len(self.flat["spatial"]), len(self.flat["c_rad"])))
+        self.stats = torch.from_numpy(np.concatenate([self.flat["c_rad"].ravel(), self.flat["c_weight"]]).astype(np.float32))
+
+    def guided_stats(self):
+        return self.stats, self.stats.numel()
+
+    def guided_end(self):
+        return self.film, 1.0 / self.waves[-1], {"samples": 0}
+
+
+def _worker(rank, port, q, WORLD):
     import torch.distributed as dist
 
     import path_tracer_amd as pt
@@ -89,7 +135,7 @@ def _worker(rank, port, q):
         sc = su.furnace_scene("plain")
         cam = pt.make_camera(su.IDENTITY, 39.5, 12, 8)
         ctx = OracleShardContext(sc, cam)
-        for name, kind, spp in (("path", pt.INTEGRATOR_PATH, 7), ("lightpath", pt.INTEGRATOR_LIGHTPATH, 9)):
+        for name, kind, spp in (("path", pt.INTEGRATOR_PATH, 7), ("lightpath", pt.INTEGRATOR_LIGHTPATH, 9)):   # at WORLD = 8 rank 7 has no `path` sample
             integ = pt.make_integrator(kind, 6, pt.MODE_MIS)
             buf = torch.zeros((8, 12, 3), dtype=torch.float64)
             film, scale, st = mg.render_sharded(ctx, integ, spp, rank, WORLD, False, dist=dist, film_buf=buf)
@@ -103,29 +149,39 @@ def _worker(rank, port, q):
         buf = torch.zeros((4, 4, 3), dtype=torch.float64)
         film, _, _ = mg.render_sharded(g, None, 15, rank, WORLD, True, dist=dist, wrap_stats=lambda p, c: p, film_buf=buf)
         out["guided"] = ([s.numpy() for s in g.seen_after_reduce], g.calls, film)
+        # ---- guided end to end: the oracle's Guider behind the driver; 48 x 32 = 6 tiles, so at WORLD = 8 two ranks idle per pass
+        gsc = pt.LoadedScene("cornell-box-guided", resx=48, resy=32, max_depth=5, integrator="guided")
+        ginteg = pt.IntegratorDesc.from_buffer_copy(gsc.integrator)
+        ginteg.spatial_threshold = 150.0
+        og = OracleGuidedContext(gsc, gsc.camera, 150.0)
+        buf = torch.zeros((32, 48, 3), dtype=torch.float64)
+        film, scale, _ = mg.render_sharded(og, ginteg, 31, rank, WORLD, True, dist=dist, wrap_stats=lambda p, c: p, film_buf=buf)
+        out["guided_oracle"] = (film, scale, og.nodes, og.summed)
         q.put((rank, out))
     finally:
         dist.barrier()
         dist.destroy_process_group()
 
 
-@pytest.fixture(scope="module")
-def two_ranks():
+@pytest.fixture(scope="module", params=WORLDS, ids=lambda w: f"world{w}")
+def ranks(request):
+    WORLD = request.param
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, port, q)) for r in range(WORLD)]
+    procs = [ctx.Process(target=_worker, args=(r, port, q, WORLD)) for r in range(WORLD)]
     for p in procs:
         p.start()
-    results = dict(q.get(timeout=240) for _ in procs)
+    results = dict(q.get(timeout=400) for _ in procs)
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    return results
+    return WORLD, results
 
 
 @pytest.mark.parametrize("name", ["path", "lightpath"])
-def test_sample_shards_reduce_to_the_unsharded_film(two_ranks, name):
+def test_sample_shards_reduce_to_the_unsharded_film(ranks, name):
+    WORLD, two_ranks = ranks
     film, scale, n, whole, wscale, wn = two_ranks[0][name]
     assert n == wn and scale == wscale
     assert whole.sum() > 0
@@ -133,7 +189,8 @@ def test_sample_shards_reduce_to_the_unsharded_film(two_ranks, name):
     np.testing.assert_allclose(film, whole, rtol=1e-12, atol=1e-12)
 
 
-def test_guided_pairs_are_dealt_once_and_reduced_every_wave_but_the_last(two_ranks):
+def test_guided_pairs_are_dealt_once_and_reduced_every_wave_but_the_last(ranks):
+    WORLD, two_ranks = ranks
     for rank in range(WORLD):
         seen, calls, film = two_ranks[rank]["guided"]
         assert len(seen) == 3
@@ -142,6 +199,29 @@ def test_guided_pairs_are_dealt_once_and_reduced_every_wave_but_the_last(two_ran
         assert calls == [("wave", 0), ("stats",), ("wave", 1), ("stats",), ("wave", 2), ("stats",), ("wave", 3)]
     # film reduce: rank 0 holds the pairs of the last wave from both ranks (8 passes x 13 tiles)
     assert np.all(two_ranks[0]["guided"][2] == 8 * 13)
+
+
+def test_guided_shards_with_statistics_exchange_render_the_unsharded_image(ranks):
+    """N ranks, each tracing its (pass, tile) pairs with the oracle's own Guider and exchanging the collector through the
+    driver's all-reduce, against the oracle's single-process render (mod.rs:70-122). The f32 sums arrive in another order
+    (and a record's stochastic-filter jitter is its path's own draw: no cross-rank RNG coupling), so trees agree up to
+    near-tie refinement decisions: equal spatial node counts within 2 %, quadtree nodes within 2 %, images to relMSE < 2e-3."""
+    import oracle_bind as ob
+    import path_tracer_amd as pt
+    WORLD, res = ranks
+    film, scale, nodes, _ = res[0]["guided_oracle"]
+    for r in range(1, WORLD):   # every rank refined the same tree in every wave, bit for bit, from the reduced statistics
+        assert res[r]["guided_oracle"][2] == nodes
+        for a, b in zip(res[r]["guided_oracle"][3], res[0]["guided_oracle"][3]):
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    gsc = pt.LoadedScene("cornell-box-guided", resx=48, resy=32, max_depth=5, integrator="guided")
+    integ = pt.IntegratorDesc.from_buffer_copy(gsc.integrator)
+    integ.spatial_threshold = 150.0
+    whole, wscale, wst = ob.OracleScene(gsc).render(gsc.camera, integ, 31)
+    assert scale == wscale and nodes[-1][0] > 3
+    assert abs(nodes[-1][0] - wst["stree_nodes"]) <= 0.02 * wst["stree_nodes"] + 2, (nodes[-1], wst)
+    a, b = film * scale, whole * wscale
+    assert abs(a.mean() / b.mean() - 1.0) < 5e-3 and ob.rel_mse(a, b) < 2e-3, (a.mean(), b.mean(), ob.rel_mse(a, b))
 
 
 def test_shard_rules_balance():

@@ -681,6 +681,56 @@ def test_bench_rccl_path_rehearsal(workload):
     assert line["n_gpus"] == 1 and line["value"] > 0 and line["roofline"]["achieved"] > 0
 
 
+_REDUCE_SCRIPT = r"""
+import os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["PT_REPO"])
+import path_tracer_amd as pt
+from path_tracer_amd import multi_gpu as mg
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29547", RANK="0", WORLD_SIZE="1")
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+dist.init_process_group("nccl", device_id=dev)
+ctx = pt.Context(0)
+for scene, kind in (("cornell-box", pt.INTEGRATOR_PATH), ("cornell-box", pt.INTEGRATOR_LIGHTPATH), ("cornell-box-guided", pt.INTEGRATOR_GUIDED)):
+    sc = pt.LoadedScene(scene, resx=64, resy=48, max_depth=6)
+    ctx.load(sc)
+    integ = pt.IntegratorDesc.from_buffer_copy(sc.integrator)
+    integ.kind = kind
+    guided = kind == pt.INTEGRATOR_GUIDED
+    buf = torch.zeros((48, 64, 3), dtype=torch.float64, device=dev)
+    sync = lambda: torch.cuda.synchronize(dev)
+    # (a) the device path: in-place all-reduce of the library's statistics, reduce of the library's film buffer
+    a, sa, _ = mg.render_sharded(ctx, integ, 15, 0, 1, guided, dist=dist, wrap_stats=mg.device_stats_tensor(torch, dev), film_buf=buf, sync=sync, collectives=True)
+    # (b) a wrapper without the typestr parameter: the film goes through the host copy and film_buf
+    wrap2 = (lambda w: (lambda p, c: w(p, c)))(mg.device_stats_tensor(torch, dev))
+    b, sb, _ = mg.render_sharded(ctx, integ, 15, 0, 1, guided, dist=dist, wrap_stats=wrap2 if guided else None, film_buf=buf, sync=sync, collectives=True)
+    # (c) no collectives at all
+    c, sc_, _ = ctx.render(integ, 15)
+    assert sa == sb == sc_ and a.shape == b.shape == c.shape == (48, 64, 3) and c.sum() > 0
+    if guided:   # free-running: f32 atomic order decides near-ties in the tree
+        assert abs(a.mean() / c.mean() - 1) < 0.02 and abs(b.mean() / c.mean() - 1) < 0.02, (a.mean(), b.mean(), c.mean())
+    else:        # the same samples; lightpath's f64 splats arrive in another order
+        np.testing.assert_allclose(a, c, rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(b, c, rtol=1e-9, atol=1e-12)
+dist.barrier()
+dist.destroy_process_group()
+print("REDUCE-OK")
+"""
+
+
+def test_render_sharded_reduces_the_film_it_renders():
+    """The multi-GPU driver with a one-rank RCCL group (the box has one GPU): the film that dist.reduce leaves on rank 0 —
+    reduced in place on the library's device buffer, or through the host copy for a caller whose wrapper cannot alias it —
+    is the film ptgpu_render returns for the same job."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, PT_REPO=str(Path(__file__).resolve().parent.parent))
+    r = subprocess.run([sys.executable, "-c", _REDUCE_SCRIPT], env=env, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0 and "REDUCE-OK" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
+
+
 # ------------------------------------------------------------------ the `pt` executable (main.rs:25-51) end to end
 @pytest.mark.parametrize("integrator", ["path", "lightpath"])
 def test_pt_cli_writes_the_film_the_abi_returns(gpu_ctx, tmp_path, integrator):
