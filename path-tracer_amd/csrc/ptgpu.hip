@@ -225,7 +225,7 @@ constexpr size_t kLdsDefaultLimit = 64 * 1024, kLdsPerCu = 160 * 1024;
 // cheaper steps win (Cornell box: extend 8.1 ms against 9.1), where every step is a round trip to L2 the wide walk's
 // fewer steps do (veach-mis, 61 492 triangles: extend 25.2 -> 22.2 ms, occlusion 22.9 -> 20.0); veach-bidir (0.7 MB) was even
 // then and is well ahead since the wide walkers take their queues as streams (path 211 -> 266, guided 140 -> 161 Msamples/s at
-// 64 spp, tools/time_scene.py), Cornell still 2 % behind. Nothing in between was measured: the line sits at the L2 side of it.
+// 64 spp, tools/time_render.py --scene veach-bidir), Cornell still 2 % behind. Nothing in between was measured: the line sits at the L2 side of it.
 constexpr size_t kWideAboveBytes = 1u << 18;
 
 int grid_for(const ptgpu_ctx* c, uint64_t n) {

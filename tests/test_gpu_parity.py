@@ -498,7 +498,7 @@ def test_guided_image_and_tree_match_oracle(gpu_ctx, name, res, spp, depth):
     """Two FREE-RUNNING renders (the lock-step comparison, which is deterministic, is tests/test_gpu_sdtree.py): same
     scene, spp and RNG streams, but the f32 atomic order of the GPU's splats differs from the oracle's, a near-tie in
     `frac < 0.01` then splits a quadtree cell on one side only, and from there the two sides draw different samples.
-    Measured on MI355X (tools/dbg_free_running.py): spatial trees equal (333/333, 151/151 nodes), directional nodes within
+    Measured on MI355X: spatial trees equal (333/333, 151/151 nodes), directional nodes within
     4 of 13 149, image means within 1e-3, block relMSE <= 1.2e-4. Bounds below = those with a margin of ~10x."""
     sc = pt.LoadedScene(name, resx=res[0], resy=res[1], max_depth=depth, integrator="guided")
     o = ob.OracleScene(sc)
