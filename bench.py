@@ -263,6 +263,19 @@ def main() -> int:
                 if kernel.split("+")[0] in kname:
                     roofline["traffic"] = int(d["hbm_bytes_per_launch"])
                     roofline["traffic_source"] = f"profiles/{cands[-1].name}"
+                    if dom == "shade" and guided:
+                        # FETCH_SIZE tallies every read request at 64 B whatever its width (profiles/r03_fetch_calibration.json:
+                        # 128-B lines, 64-B and 32-B scattered reads alike), so the guide's x2 holds for full lines only. The
+                        # kernel's full-line reads are its streams (80 B of state + 24 B of hit record per segment); what is
+                        # left of the requests are 32-byte sector reads (jump-table entries, quadtree nodes, table rows).
+                        stream_reads = my["segments"] * (80 + 24) / launches
+                        raw = d["read_bytes_per_launch"] / 2.0
+                        scattered_requests = max(0.0, raw - stream_reads / 2.0) / 64.0
+                        calibrated = stream_reads + scattered_requests * 32.0 + d["write_bytes_per_launch"]
+                        roofline["traffic_calibrated"] = int(calibrated)
+                        roofline["traffic_calibrated_over_layout"] = round(calibrated / (layout_bytes / launches), 3)
+                        roofline["traffic_note"] = ("traffic = FETCH_SIZE x 2 + WRITE_SIZE as MI355X_MICROARCH.md prescribes for coalesced streams; traffic_calibrated prices "
+                                                    "the requests beyond the kernel's coalesced streams as the 32-byte sector reads they are (tools/calib_fetch.hip)")
     # The record pass of one batch runs beside the walk of the next (second stream): a kernel's launch duration in the timed
     # region is therefore its time on a SHARED GPU. One more, untimed, step with the streams serialised gives the dominant
     # kernel's duration with the GPU to itself (what a roofline fraction of the kernel means); reported beside, never instead.

@@ -213,10 +213,12 @@ int ptgpu_guided_captured_records(ptgpu_ctx* ctx, uint32_t* out_words, uint64_t 
  * ptgpu_trace_batch doubles as the extend micro-benchmark: it resets the stage timers, and with profiling on reports the
  * walk kernel's time as PTGPU_STAGE_EXTEND; with the census on it adds nodes popped / triangles tested to census[0..1]. */
 int ptgpu_trace_batch(ptgpu_ctx* ctx, const float* rays, uint32_t n, ptgpu_hit* hits_out);
-/* No counterpart in the reference. ptgpu_trace_batch for callers that cannot allocate device memory (code under HIP
- * graph capture, tight serving loops, harnesses that forbid hipMalloc): identical results, but the device staging of the
- * rays and hit records is a static 15 MiB array inside the library (one copy per GPU, held until the process ends)
- * instead of a per-call hipMalloc/hipFree, and no timer or census is taken. n <= 262144 (PTGPU_NOALLOC_MAX_RAYS), more
+/* No counterpart in the reference. ptgpu_trace_batch for callers that cannot allocate device memory (tight serving loops,
+ * harnesses that forbid hipMalloc, code that must not disturb a captured graph's memory): identical results, but the
+ * device staging of the rays and hit records is a static 15 MiB array inside the library (one copy per GPU, held until
+ * the process ends) instead of a per-call hipMalloc/hipFree, and no timer or census is taken. It allocates nothing; it
+ * is NOT itself capturable: it copies from and to the caller's pageable host buffers and waits for the stream
+ * (hipStreamSynchronize), neither of which is legal inside a HIP graph capture. n <= 262144 (PTGPU_NOALLOC_MAX_RAYS), more
  * fails with PTGPU_E_LIMIT. All contexts on one GPU share that array: calls that overlap on one GPU race. */
 #define PTGPU_NOALLOC_MAX_RAYS 262144u
 int ptgpu_trace_batch_noalloc(ptgpu_ctx* ctx, const float* rays, uint32_t n, ptgpu_hit* hits_out);

@@ -137,6 +137,7 @@ struct ptgpu_ctx {
     // render workspace
     uint32_t batch_paths = 0;  // 0 = default
     uint32_t capacity = 0;
+    uint64_t fallback_cap = 0, fallback_unit = 0;  // path / lightpath: the batch size that fit where the device had less memory left, and the pass size it was found for
     StateSet set_a, set_b;
     DevBuf<float4> d_hit_tb;
     DevBuf<uint2> d_hit_prim;
@@ -252,17 +253,23 @@ int ensure_workspace(ptgpu_ctx* c, uint32_t cap) {
 }
 // ensure_workspace for `cap` paths or, where the device has not that much memory left, for the largest whole multiple
 // of `unit` paths (one sample pass of the image) that it has, halving until it fits.
-int ensure_workspace_or_smaller(ptgpu_ctx* c, uint64_t cap, uint64_t unit) {
+// `headroom`: bytes that must stay free after it (the film and the tables are allocated later; at least 2 GB).
+int ensure_workspace_or_smaller(ptgpu_ctx* c, uint64_t cap, uint64_t unit, size_t headroom) {
+    // a context that had to fall back starts the next render of the same image at the size that fit, instead of freeing
+    // the working workspace and failing its way down from the top again (multi-GB hipFree / hipMalloc per render)
+    if (c->fallback_unit == unit && c->fallback_cap != 0 && cap > c->fallback_cap) cap = std::max<uint64_t>(unit, (c->fallback_cap / unit) * unit);
     if (c->capacity == cap && c->set_a.cols.p) return PTGPU_OK;  // the workspace of the previous render
+    headroom = std::max(headroom, (size_t)2 << 30);
     for (;;) {
         const int rc = ensure_workspace(c, (uint32_t)cap);
         size_t free_b = 0, total_b = 0;
-        // (a workspace that leaves less than 2 GB free is too large as well: tables and the film come after it)
-        if (rc == PTGPU_OK && (cap <= unit || hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b >= ((size_t)2 << 30))) return rc;
+        if (rc == PTGPU_OK && (cap <= unit || hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b >= headroom)) return rc;
         const bool out_of_memory = rc == PTGPU_OK || hipGetLastError() == hipErrorOutOfMemory;
         c->capacity = 0;  // whatever was allocated is not a consistent workspace
         if (!out_of_memory || cap <= unit) return rc;
         cap = std::max(unit, (cap / 2 / unit) * unit);
+        c->fallback_cap = cap;
+        c->fallback_unit = unit;
     }
 }
 ShadowCols shadow_view(ptgpu_ctx* c) {
@@ -657,7 +664,7 @@ int ptgpu_scene_create(ptgpu_ctx* c, const ptgpu_scene_desc* desc) {
     c->resident_blocks.clear();
     if (c->bvh_lds_mode[0] > kLdsPerCu) return fail(PTGPU_E_LIMIT, "scene_create: traversal stacks exceed the CU's LDS");
     if (std::max(c->bvh_lds_mode[0], c->have_wide ? c->bvh_lds_mode[1] : 0) > kLdsDefaultLimit) {
-        const int lds_b = (int)c->bvh_lds_mode[0], lds_w = (int)std::max(c->bvh_lds_mode[1], (size_t)1);
+        const int lds_b = (int)c->bvh_lds_mode[0], lds_w = c->have_wide ? (int)std::max(c->bvh_lds_mode[1], (size_t)1) : 1;  // (no wide image: its kernels are never launched)
 #define PT_SET_LDS(kernel)                                                                                             \
     HIP_TRY(hipFuncSetAttribute((const void*)kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b)); \
     HIP_TRY(hipFuncSetAttribute((const void*)kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b)); \
@@ -1051,7 +1058,8 @@ int render_path_like(ptgpu_ctx* c, const ptgpu_integrator_desc* integ, uint32_t 
     const uint64_t my_samples = spp > shard_index ? ((uint64_t)spp - shard_index + shard_count - 1) / shard_count : 0;
     HIP_TRY(hipMemsetAsync(c->d_film.p, 0, c->d_film.n * sizeof(double), c->stream));
     if (my_samples == 0 || integ->max_depth == 0) return PTGPU_OK;
-    int rc = ensure_workspace_or_smaller(c, pick_capacity(c, my_samples * npix), npix);
+    // (the device film exists by now; what comes after the workspace is the packed film, 24 bytes per pixel, and the wavelength table)
+    int rc = ensure_workspace_or_smaller(c, pick_capacity(c, my_samples * npix), npix, (size_t)npix * 24u + ((size_t)256 << 20));
     if (rc != PTGPU_OK) return rc;
     rc = upload_lambda_table(c, golden_iterates(spp));
     if (rc != PTGPU_OK) return rc;

@@ -285,7 +285,10 @@ def test_guided_render_in_lock_step_with_oracle(gpu_ctx, name, res, spp, depth, 
             # per leaf, not only in total: identical on the Cornell box and veach-mis (worst 2e-5 over all waves); on veach-bidir
             # at depth 32 the re-routed paths (above) carry whole records from one leaf to another: measured 85 % of the
             # leaves within 1e-3, median 5e-6, worst 2e-2
-            assert np.median(rel_leaf) < 1e-4 and (rel_leaf <= 1e-3).mean() >= 0.8 and rel_leaf.max() < 0.1, (w, np.median(rel_leaf), rel_leaf.max())
+            if heavy.sum() >= 8:
+                assert np.median(rel_leaf) < 1e-4 and (rel_leaf <= 1e-3).mean() >= 0.8 and rel_leaf.max() < 0.1, (w, np.median(rel_leaf), rel_leaf.max())
+            else:   # the first waves' handful of leaves: each holds a good part of all records, re-routed ones included
+                assert rel_leaf.max() < 2e-3, (w, rel_leaf)
             print(f"wave {w}: per-leaf collector sums, {int(heavy.sum())} leaves of weight >= 50: within 1e-3 {(rel_leaf <= 1e-3).mean():.4f}, "
                   f"median {np.median(rel_leaf):.2e}, worst {rel_leaf.max():.2e}")
         # both refine from the GPU's statistics
