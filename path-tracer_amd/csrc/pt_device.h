@@ -1021,10 +1021,11 @@ struct Tri {
 };
 PT_HD int tri_material(const Tri& t) { return tag_material(t.tag); }
 PT_HD bool tri_has_normals(const Tri& t) { return (t.tag & kTagNormalsBit) != 0; }
-PT_D Tri load_tri(const SceneDev& sc, uint32_t k) {
-    const float4 a = sc.tri_v[3 * k], b = sc.tri_v[3 * k + 1], c = sc.tri_v[3 * k + 2];
+PT_D Tri load_tri_from(const float4* tri_v, uint32_t k) {  // tri_v: the scene's array, or a copy of it in LDS (small scenes)
+    const float4 a = tri_v[3 * k], b = tri_v[3 * k + 1], c = tri_v[3 * k + 2];
     return Tri{mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), f2u(a.w), f2u(c.w)};
 }
+PT_D Tri load_tri(const SceneDev& sc, uint32_t k) { return load_tri_from(sc.tri_v, k); }
 struct Surface {  // SceneInteraction (scene.rs:65-86,192-217)
     V3 blo, bhi;   // error box around p
     V3 ng;
@@ -1032,9 +1033,9 @@ struct Surface {  // SceneInteraction (scene.rs:65-86,192-217)
     Tri tri;
 };
 PT_HD V3 surf_p(const Surface& s) { return (s.blo + s.bhi) / 2.0f; }
-PT_D Surface make_surface(const SceneDev& sc, uint32_t prim, float b0, float b1, float b2) {
+PT_D Surface make_surface_from(const SceneDev& sc, const float4* tri_v, uint32_t prim, float b0, float b1, float b2) {
     Surface s;
-    s.tri = load_tri(sc, prim);
+    s.tri = load_tri_from(tri_v, prim);
     const float b[3] = {b0, b1, b2};
     V3 p = tri_point(s.tri.p0, s.tri.p1, s.tri.p2, b);
     V3 abs_sum = absv(s.tri.p0) * b0 + absv(s.tri.p1) * b1 + absv(s.tri.p2) * b2;
@@ -1050,6 +1051,7 @@ PT_D Surface make_surface(const SceneDev& sc, uint32_t prim, float b0, float b1,
     s.bhi = p + err;
     return s;
 }
+PT_D Surface make_surface(const SceneDev& sc, uint32_t prim, float b0, float b1, float b2) { return make_surface_from(sc, sc.tri_v, prim, b0, b1, b2); }
 // KINDS = bit mask of the material kinds the scene uses (1 << MAT_*), fixed at scene creation. The shade kernels are
 // compiled per mask so that a scene without, say, conductors does not carry their registers and branches.
 // (spec_lookup: see SpecTab in pt_types.h.)
@@ -1061,9 +1063,12 @@ PT_D Spec spec_lookup(const SpecTab& st, uint32_t spectrum, uint32_t row) {
     s.v[4] = b.x; s.v[5] = b.y; s.v[6] = b.z; s.v[7] = b.w;
     return s;
 }
+struct MatHead {  // what shading needs of a MaterialDev beyond the spectral table
+    int kind;
+    float roughness;
+};
 template <int KINDS>
-PT_D Bsdf make_bsdf(const SceneDev& sc, const SpecTab& st, int material, uint32_t row) {
-    const MaterialDev m = sc.materials[material];
+PT_D Bsdf make_bsdf_head(const SpecTab& st, MatHead m, int material, uint32_t row) {
     Bsdf b;
     b.kind = m.kind;
     if (KINDS == (1 << MAT_LAMBERTIAN)) b.kind = MAT_LAMBERTIAN;
@@ -1076,6 +1081,10 @@ PT_D Bsdf make_bsdf(const SceneDev& sc, const SpecTab& st, int material, uint32_
     b.a = spec_lookup(st, 2u * (uint32_t)material, row);
     b.b = (b.kind == MAT_CONDUCTOR) ? spec_lookup(st, 2u * (uint32_t)material + 1u, row) : spec_splat(0.0f);
     return b;
+}
+template <int KINDS>
+PT_D Bsdf make_bsdf(const SceneDev& sc, const SpecTab& st, int material, uint32_t row) {
+    return make_bsdf_head<KINDS>(st, MatHead{sc.materials[material].kind, sc.materials[material].roughness}, material, row);
 }
 
 // ------------------------------------------------------------------ area lights (pt/src/lighting.rs:12-169)
@@ -1099,15 +1108,15 @@ struct LightPoint {  // common part of LiSample / LeSample
     float pmf;
 };
 // Scene::choose_light (scene.rs:257-268): uniform over emissive triangles.
-PT_D bool choose_light(const SceneDev& sc, float u, Tri& t, float& pmf) {
+PT_D bool choose_light_from(const SceneDev& sc, const float4* light_v, float u, Tri& t, float& pmf) {
     if (sc.n_emissive_tris == 0) return false;
     uint32_t idx = (uint32_t)((float)sc.n_emissive_tris * u);
     if (idx >= sc.n_emissive_tris) idx = sc.n_emissive_tris - 1;
-    const float4 a = sc.light_v[3 * idx], b = sc.light_v[3 * idx + 1], c = sc.light_v[3 * idx + 2];
-    t = Tri{mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), f2u(a.w), f2u(c.w)};
+    t = load_tri_from(light_v, idx);
     pmf = 1.0f / (float)sc.n_emissive_tris;
     return true;
 }
+PT_D bool choose_light(const SceneDev& sc, float u, Tri& t, float& pmf) { return choose_light_from(sc, sc.light_v, u, t, pmf); }
 struct LiSample {
     V3 blo, bhi, n, wl;
     float pdf;

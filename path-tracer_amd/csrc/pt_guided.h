@@ -66,11 +66,29 @@ struct alignas(32) SNode {
     uint2 child;
     uint2 pad;
 };
+// Two levels of a sampling quadtree in one 128-byte line (PT_TWO_LEVEL): the node's own four sums and links, then the four
+// sums and the links of each of its interior children. A record exists for every interior node at an even depth; links
+// between records (glink) are record indices relative to the leaf's first record, which sits at the arena offset of the
+// leaf's first node (a leaf has no more records than nodes). A descent fetches one line per two levels: the second level's
+// 24 bytes are in the line the first level's fetch has just brought in. Built from the one-level arena by k_build_two_level.
+struct alignas(128) SNode2 {
+    float4 rad;
+    uint2 child;   // the node's four one-level links: only == 0 (leaf cell) matters here
+    uint2 aux;     // .x: the node's index in the one-level arena (the builder's queue)
+    float4 grad[4];
+    uint2 glink[4];
+};
+static_assert(sizeof(SNode2) == 128, "one line");
+#ifndef PT_TWO_LEVEL
+#define PT_TWO_LEVEL 0
+#endif
+
 struct SdTreeDev {
     const uint4* snodes;
     const uint2* top;  // {entry, sampler word of the leaf}: jump table over the first kStreeTopLevels decisions (sdtree_host.h)
     const uint4* leaf_info;
     const SNode* s_node;  // sampling arena: a node's four child sums and four child links in one 32-byte record (one line per level)
+    const SNode2* s_node2;  // the same trees, two levels per 128-byte record (PT_TWO_LEVEL)
     float4* c_rad;
     const uint2* c_child;
     float4* c_lazy;          // per collector node: radiance owed to ALL cells below child c (binned record pass; k_push_lazy)
@@ -350,6 +368,143 @@ PT_D float dtree_walk(const SdTreeDev& t, uint4 leaf, bool sample, Rng& rng, V2&
     return result * kInvFourPi;
 }
 
+// dtree_pdf / dtree_walk over the two-level records: the same choices, the same factors in the same order.
+PT_D float dtree_pdf2(const SdTreeDev& t, uint4 leaf, V2 p, float* scales) {
+    if (leaf.z) return kInvFourPi;
+    int n = 0;
+    const SNode2* rec = t.s_node2 + leaf.x;
+    Cell cell{0, 0, 0};
+    float4 r = rec->rad;
+    uint2 links = rec->child;
+    float result;
+    for (bool second = false;; second = !second) {
+        Cell child;
+        const int c = cell_child_of(cell, p, child);
+        const float rc = comp4(r, c);
+        if (rc == 0.0f) {
+            result = 0.0f;
+            break;
+        }
+        const float scale = 4.0f * rc / ((((0.0f + r.x) + r.y) + r.z) + r.w);
+        const uint32_t link = child_link(links, c);
+        if (link == 0 || child.level >= kMaxQuadLevel) {
+            result = scale;
+            break;
+        }
+        scales[(n++) * kScaleStride] = scale;
+        cell = child;
+        if (!second) {
+            r = rec->grad[c];
+            links = rec->glink[c];
+        } else {
+            rec = t.s_node2 + leaf.x + link;
+            r = rec->rad;
+            links = rec->child;
+        }
+    }
+    for (int i = n - 1; i >= 0; i--) result = scales[i * kScaleStride] * result;
+    return result * kInvFourPi;
+}
+PT_D float dtree_walk2(const SdTreeDev& t, uint4 leaf, bool sample, Rng& rng, V2& sq, float* scales, float4 root_rad, uint2 root_child) {
+    if (leaf.z) {
+        if (sample) {
+            const float a = rng_f32(rng), b = rng_f32(rng);
+            sq = V2{a, b};
+        }
+        return kInvFourPi;
+    }
+    int n = 0;
+    const SNode2* rec = t.s_node2 + leaf.x;
+    Cell cell{0, 0, 0};
+    float result;
+    bool redo = false;
+    float4 r = root_rad;
+    uint2 links = root_child;
+    for (bool second = false;; second = !second) {
+        int c;
+        Cell child;
+        if (sample) {
+            c = sample_discrete4(rng_f32(rng), r.x, r.y, r.z, r.w);
+            child = Cell{2 * cell.ix + (uint32_t)(c & 1), 2 * cell.iy + (uint32_t)(c >> 1), cell.level + 1};
+        } else {
+            c = cell_child_of(cell, sq, child);
+        }
+        const float rc = comp4(r, c);
+        if (rc == 0.0f) {
+            if (!sample) {
+                result = 0.0f;
+                break;
+            }
+            redo = true;
+        }
+        const float scale = 4.0f * rc / ((((0.0f + r.x) + r.y) + r.z) + r.w);
+        const uint32_t link = child_link(links, c);
+        cell = child;
+        if (link == 0 || child.level >= kMaxQuadLevel) {
+            result = scale;
+            break;
+        }
+        scales[(n++) * kScaleStride] = scale;
+        if (!second) {  // the child's sums and links: same line as the node's
+            r = rec->grad[c];
+            links = rec->glink[c];
+        } else {  // the grandchild's record
+            rec = t.s_node2 + leaf.x + link;
+            r = rec->rad;
+            links = rec->child;
+        }
+    }
+    if (sample) {
+        const float a = rng_f32(rng), b = rng_f32(rng);
+        const Box2 cb = cell_box(cell);
+        V2 s = cb.lo + V2{a, b} * box2_extent(cb);
+        s = min2(s, cb.hi - V2{kEps, kEps});
+        sq = clamp2(s, V2{0.0f, 0.0f}, V2{1.0f, 1.0f});
+        if (redo || !(sq.x >= cb.lo.x && sq.x < cb.hi.x && sq.y >= cb.lo.y && sq.y < cb.hi.y)) return dtree_pdf2(t, leaf, sq, scales);
+    }
+    for (int i = n - 1; i >= 0; i--) result = scales[i * kScaleStride] * result;
+    return result * kInvFourPi;
+}
+
+// Builds the two-level records of every spatial leaf's sampling quadtree from the one-level arena: one thread per leaf,
+// breadth first over the interior nodes at even depths, the records themselves serving as the queue (aux.x = node).
+__global__ __launch_bounds__(kBlock) void k_build_two_level(const SNode* s1, SNode2* s2, const uint32_t* s_off, uint32_t n_leaves) {
+    const uint32_t leaf = blockIdx.x * blockDim.x + threadIdx.x;
+    if (leaf >= n_leaves) return;
+    const uint32_t base = s_off[leaf];
+    const SNode* in = s1 + base;
+    SNode2* out = s2 + base;
+    out[0].aux = make_uint2(0u, 0u);
+    uint32_t next = 1;
+    for (uint32_t r = 0; r < next; r++) {
+        const uint32_t node = out[r].aux.x;
+        const SNode N = in[node];
+        SNode2 rec;
+        rec.rad = N.rad;
+        rec.child = N.child;
+        rec.aux = make_uint2(node, 0u);
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            rec.grad[c] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            uint32_t gl[4] = {0u, 0u, 0u, 0u};
+            const uint32_t link = child_link(N.child, c);
+            if (link != 0) {
+                const SNode C = in[link];
+                rec.grad[c] = C.rad;
+                for (int g = 0; g < 4; g++) {
+                    const uint32_t l2 = child_link(C.child, g);
+                    if (l2 != 0) {
+                        out[next].aux = make_uint2(l2, 0u);
+                        gl[g] = next++;
+                    }
+                }
+            }
+            rec.glink[c] = make_uint2(gl[0] | (gl[1] << 16), gl[2] | (gl[3] << 16));
+        }
+        out[r] = rec;
+    }
+}
+
 // Guider::sample (path_guiding/mod.rs:315-368). `sampler_word` and `root` are the spatial leaf's sampler word and its
 // quadtree's first node, fetched by the caller while it did other work (unused for iteration 0 / specular surfaces).
 PT_D bool guider_sample(const SdTreeDev& t, const Bsdf& bsdf, const Frame& fr, V3 ng, V3 wo, Rng& rng, float* lds_scales, uint32_t sampler_word, const SNode& root,
@@ -373,7 +528,11 @@ PT_D bool guider_sample(const SdTreeDev& t, const Bsdf& bsdf, const Frame& fr, V
         PT_TICK(5);
     }
     PT_TICK(16);
+#if PT_TWO_LEVEL
+    const float tree_pdf = dtree_walk2(t, leaf, use_tree, rng, sq, lds_scales, root.rad, root.child);
+#else
     const float tree_pdf = dtree_walk(t, leaf, use_tree, rng, sq, lds_scales, root);
+#endif
     PT_TICK(6);
     if (use_tree) {
         s.wi = square_to_dir(sq);
@@ -650,8 +809,23 @@ PT_D void stage_write_out(float4* lines, float4* lo, float4* hi, uint32_t line) 
     asm volatile("" ::: "memory");  // ... and the block's next use below
 }
 
+// Small scenes (the Cornell box: 24 triangles, 2 of them lights, 5 materials) keep their triangles, their light table and
+// their material heads in LDS for the shade kernel (SMALL): what this kernel is short of is the CU's vector-memory front
+// end — every 16-byte-per-lane load holds the address pipeline a good 16 cycles whatever it hits — and LDS is a second,
+// independent pipe. Same values from another place; a separate instantiation, so that no load becomes a flat one.
+constexpr uint32_t kSmallTris = 64, kSmallLights = 16, kSmallMats = 16;
+template <bool SMALL>
+struct SmallSceneLds {
+    float4 tri[3 * kSmallTris];
+    float4 light[3 * kSmallLights];
+    MatHead mat[kSmallMats];
+};
+template <>
+struct SmallSceneLds<false> {};
+PT_HD bool scene_is_small(uint32_t n_tris, uint32_t n_emissive_tris, uint32_t n_materials) { return n_tris <= kSmallTris && n_emissive_tris <= kSmallLights && n_materials <= kSmallMats; }
+
 // One iteration of PathGuidingIntegrator::random_walk's loop body (mod.rs:139-278).
-template <int KINDS>
+template <int KINDS, bool SMALL>
 __global__ __launch_bounds__(kBlock, KINDS != 7 ? PT_GUIDED_DIFFUSE_WAVES : PT_SHADE_WAVES) void k_shade_guided(SceneDev sc, SdTreeDev tree, RenderParams rp, GuidedParams gp, PathCols in, HitCols hit, PathCols out,
                                                          ShadowCols sh, const RoundCounters* cur, RoundCounters* nxt, const uint32_t* cur_top, uint32_t* nxt_top) {
     __shared__ BlockAlloc3 sm_alloc;
@@ -667,6 +841,13 @@ __global__ __launch_bounds__(kBlock, KINDS != 7 ? PT_GUIDED_DIFFUSE_WAVES : PT_S
 #define PT_STAGE_LO reinterpret_cast<float4*>(sm_scales + (threadIdx.x / 64u) * kScaleWaveFloats)
 #define PT_STAGE_HI (sm_stage_hi + (threadIdx.x / 64u) * 4u * 64u)
     PT_TICK_INIT();
+    __shared__ SmallSceneLds<SMALL> sm_scene;
+    if constexpr (SMALL) {
+        for (uint32_t k = threadIdx.x; k < 3u * sc.n_tris; k += kBlock) sm_scene.tri[k] = sc.tri_v[k];
+        for (uint32_t k = threadIdx.x; k < 3u * sc.n_emissive_tris; k += kBlock) sm_scene.light[k] = sc.light_v[k];
+        for (uint32_t k = threadIdx.x; k < sc.n_materials; k += kBlock) sm_scene.mat[k] = MatHead{sc.materials[k].kind, sc.materials[k].roughness};
+        __syncthreads();
+    }
     uint32_t n_shaded = 0, n_skipped = 0;
     const uint32_t n_bottom = cur->n_active;
     const uint32_t n = n_bottom + *cur_top;
@@ -688,6 +869,10 @@ __global__ __launch_bounds__(kBlock, KINDS != 7 ? PT_GUIDED_DIFFUSE_WAVES : PT_S
         V3 o = mk3(0, 0, 0), d = mk3(0, 0, 1);
         uint32_t flags = 0, pid = 0, nverts = 0;
         bool stored = false, miss_vertex = false;  // stored: this lane fills vertex row nverts - 1 of its path in this trip
+        V3 park_p = mk3(0, 0, 0), park_wi = mk3(0, 0, 1);
+        float park_pdf = 0.0f;
+        Spec park_f = spec_splat(0.0f);
+        uint32_t park_bits = 0;
         Spec beta = spec_splat(0.0f);
         uint4 rp4 = make_uint4(0, 0, 0, 0);
         if (valid) {
@@ -716,7 +901,9 @@ __global__ __launch_bounds__(kBlock, KINDS != 7 ? PT_GUIDED_DIFFUSE_WAVES : PT_S
                 const float4 tb = hit.tb[i];
                 beta = fresh ? spec_splat(1.0f) : load_spec(in.beta0, in.beta1, i);
                 const uint32_t row = rp4.w & 0xffffu;  // wavelength-table row of this path
-                const Surface sf = make_surface(sc, prim, tb.y, tb.z, tb.w);
+                Surface sf;
+                if constexpr (SMALL) sf = make_surface_from(sc, sm_scene.tri, prim, tb.y, tb.z, tb.w);
+                else sf = make_surface(sc, prim, tb.y, tb.z, tb.w);
                 const int material = tag_material(prim_tag.y);
                 uint32_t depth = flags & FLAG_DEPTH_MASK;
                 if (material < 0) {
@@ -730,7 +917,9 @@ __global__ __launch_bounds__(kBlock, KINDS != 7 ? PT_GUIDED_DIFFUSE_WAVES : PT_S
                     flags &= ~FLAG_PASS_MASK;
                     const V3 wo = -d;
                     const V3 p = surf_p(sf);
-                    const Bsdf bsdf = make_bsdf<KINDS>(sc, rp.spec, material, row);
+                    Bsdf bsdf;
+                    if constexpr (SMALL) bsdf = make_bsdf_head<KINDS>(rp.spec, sm_scene.mat[material], material, row);
+                    else bsdf = make_bsdf<KINDS>(sc, rp.spec, material, row);
                     const bool specular = bsdf_is_specular(bsdf);
                     const bool spec_bounce = (flags & FLAG_SPECULAR_BOUNCE) != 0;
                     Spec emitted = spec_splat(0.0f);
@@ -765,7 +954,8 @@ __global__ __launch_bounds__(kBlock, KINDS != 7 ? PT_GUIDED_DIFFUSE_WAVES : PT_S
                         const float u1d = rng_f32(rng);
                         ua = rng_f32(rng);
                         ub = rng_f32(rng);
-                        have_light = choose_light(sc, u1d, lt, pmf);
+                        if constexpr (SMALL) have_light = choose_light_from(sc, sm_scene.light, u1d, lt, pmf);
+                        else have_light = choose_light(sc, u1d, lt, pmf);
                     }
                     Spec le = spec_splat(0.0f);
                     if (have_light) le = spec_lookup(rp.spec, rp.spec.emission_base + lt.mesh, row);
@@ -776,7 +966,12 @@ __global__ __launch_bounds__(kBlock, KINDS != 7 ? PT_GUIDED_DIFFUSE_WAVES : PT_S
                     root.child = make_uint2(0u, 0u);
                     if (guided_lane) {
                         sampler_word = stree_resolve(tree, top_entry, p);
+#if PT_TWO_LEVEL
+                        root.rad = tree.s_node2[sampler_word & 0x7fffffffu].rad;
+                        root.child = tree.s_node2[sampler_word & 0x7fffffffu].child;
+#else
                         root = tree.s_node[sampler_word & 0x7fffffffu];
+#endif
                     }
                     PT_TICK(3);
                     if (have_light) {
@@ -826,8 +1021,13 @@ __global__ __launch_bounds__(kBlock, KINDS != 7 ? PT_GUIDED_DIFFUSE_WAVES : PT_S
 #pragma unroll
                         for (int k = 0; k < NSW; k++) fw.v[k] = bs.f.v[k] / bs.pdf;
                         if (!specular && nverts < gp.n_rows) {
-                            // every lane of the wave that descends a quadtree in this trip has done so: the factors' space is free
-                            stage_vertex(PT_STAGE_LO, __lane_id(), p, bs.wi, bs.pdf, fw, has_emitted, has_nee);
+                            // pieces 0-3 of the line share LDS with the wave's pdf factors: they are parked below, at the
+                            // wave-uniform point behind this divergent block, where every lane is done with its factors
+                            park_p = p;
+                            park_wi = bs.wi;
+                            park_pdf = bs.pdf;
+                            park_f = fw;
+                            park_bits = (has_emitted ? 1u : 0u) | (has_nee ? 2u : 0u);
                             stored = true;
                             want_shadow = has_nee;
                             nverts++;
@@ -852,7 +1052,11 @@ __global__ __launch_bounds__(kBlock, KINDS != 7 ? PT_GUIDED_DIFFUSE_WAVES : PT_S
             }
             rp4.w = (rp4.w & 0xffffu) | (nverts << 16);
         }
+        // Every lane of the wave is here (the block above is closed, and what follows is wave-wide ballots and shuffles):
+        // no lane can still be reading its column of pdf factors when another lane's line pieces land on it.
+        __builtin_amdgcn_wave_barrier();
         if (miss_vertex) stage_vertex(PT_STAGE_LO, __lane_id(), o + d * 10000.0f, d, 1.0f, spec_splat(1.0f), false, false);
+        else if (stored) stage_vertex(PT_STAGE_LO, __lane_id(), park_p, park_wi, park_pdf, park_f, (park_bits & 1u) != 0, (park_bits & 2u) != 0);
         stage_write_out(gp.vtx.lines, PT_STAGE_LO, PT_STAGE_HI, stored ? (nverts - 1u) * gp.vtx.n_paths + pid : kNoLine);
         PT_TICK(8);
         uint32_t a_slot, s_slot;
@@ -1139,7 +1343,11 @@ __global__ __launch_bounds__(kBlock) void k_guided_selfcheck(SdTreeDev tree, uin
     // (b) fused
     Rng rb = rng;
     V2 sq_b = V2{0.0f, 0.0f};
+#if PT_TWO_LEVEL
+    const float pdf_b = dtree_walk2(tree, leaf, true, rb, sq_b, scales, tree.s_node2[leaf.x].rad, tree.s_node2[leaf.x].child);
+#else
     const float pdf_b = dtree_walk(tree, leaf, true, rb, sq_b, scales, tree.s_node[leaf.x]);
+#endif
     if (!leaf.z) atomicAdd(counts + 0, 1ull);
     if (f2u(sq_a.x) != f2u(sq_b.x) || f2u(sq_a.y) != f2u(sq_b.y) || ra.state != rb.state) atomicAdd(counts + 1, 1ull);
     if (f2u(pdf_a) != f2u(pdf_b)) atomicAdd(counts + 2, 1ull);
@@ -1147,7 +1355,11 @@ __global__ __launch_bounds__(kBlock) void k_guided_selfcheck(SdTreeDev tree, uin
     V2 sq_c = V2{rng_f32(rng), rng_f32(rng)};
     const float pdf_c = dtree_pdf(tree, leaf, sq_c, scales);
     Rng rc = rng;
+#if PT_TWO_LEVEL
+    const float pdf_d = dtree_walk2(tree, leaf, false, rc, sq_c, scales, tree.s_node2[leaf.x].rad, tree.s_node2[leaf.x].child);
+#else
     const float pdf_d = dtree_walk(tree, leaf, false, rc, sq_c, scales, tree.s_node[leaf.x]);
+#endif
     if (f2u(pdf_c) != f2u(pdf_d) || rc.state != rng.state) atomicAdd(counts + 3, 1ull);
 }
 
@@ -1170,11 +1382,18 @@ __global__ __launch_bounds__(kBlock) void k_guided_probe(SdTreeDev tree, const f
     float* scales = scales_of(sm_scales, threadIdx.x);
     Rng rng = rng_init_pixel(i & 0xffffu, i >> 16, seed);
     V2 sq = V2{0.0f, 0.0f};
+    V2 q = V2{query[2 * (size_t)i], query[2 * (size_t)i + 1]};
+    Rng unused;
+#if PT_TWO_LEVEL
+    const float pdf_s = dtree_walk2(tree, leaf, true, rng, sq, scales, tree.s_node2[leaf.x].rad, tree.s_node2[leaf.x].child);
+    unused = rng;
+    const float pdf_q = dtree_walk2(tree, leaf, false, unused, q, scales, tree.s_node2[leaf.x].rad, tree.s_node2[leaf.x].child);
+#else
     const SNode root = tree.s_node[leaf.x];
     const float pdf_s = dtree_walk(tree, leaf, true, rng, sq, scales, root);
-    V2 q = V2{query[2 * (size_t)i], query[2 * (size_t)i + 1]};
-    Rng unused = rng;
+    unused = rng;
     const float pdf_q = dtree_walk(tree, leaf, false, unused, q, scales, root);
+#endif
     uint32_t* o = out + 16 * (size_t)i;
     o[0] = leaf_id; o[1] = f2u(sq.x); o[2] = f2u(sq.y); o[3] = f2u(pdf_s); o[4] = f2u(pdf_q);
     o[5] = (uint32_t)rng.state; o[6] = (uint32_t)(rng.state >> 32); o[7] = word2 != word ? 1u : 0u;

@@ -66,6 +66,7 @@ struct SceneDev {
     const float* d65;                  // CIE_D65_F32[471]
     const double* cie_xyz;             // CIE_XYZ_F64[471][3]
     uint32_t n_nodes, n_tris, n_emissive_tris, n_emissive_meshes;
+    uint32_t n_materials;
     uint32_t lds_nodes;                // != 0: the kernels copy the node array (n_nodes * 32 B, small scenes) into LDS behind the stacks (bvh_stage_nodes)
     uint32_t bvh_stack;                // LDS stack entries per ray = tree depth + 1 (kernels get 256 * bvh_stack * 4 B of dynamic LDS)
     // four-wide image of the same tree (bvh_build.h: WideNode; eight float4 per node), walked by the WIDE kernel variants

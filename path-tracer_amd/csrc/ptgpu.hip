@@ -638,6 +638,7 @@ int ptgpu_scene_create(ptgpu_ctx* c, const ptgpu_scene_desc* desc) {
     s.n_nodes = (uint32_t)n_nodes;
     s.n_tris = (uint32_t)n_tris;
     s.n_emissive_tris = (uint32_t)emissive_ids.size();
+    s.n_materials = (uint32_t)mats.size();
     s.n_emissive_meshes = n_emissive_meshes;
     s.bvh_stack = bvh_depth + 1;
     s.lds_nodes = (n_nodes * 32 <= kLdsNodeBudget) ? 1u : 0u;
