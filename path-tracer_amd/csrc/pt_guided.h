@@ -809,21 +809,6 @@ PT_D void stage_write_out(float4* lines, float4* lo, float4* hi, uint32_t line) 
     asm volatile("" ::: "memory");  // ... and the block's next use below
 }
 
-// Small scenes (the Cornell box: 24 triangles, 2 of them lights, 5 materials) keep their triangles, their light table and
-// their material heads in LDS for the shade kernel (SMALL): what this kernel is short of is the CU's vector-memory front
-// end — every 16-byte-per-lane load holds the address pipeline a good 16 cycles whatever it hits — and LDS is a second,
-// independent pipe. Same values from another place; a separate instantiation, so that no load becomes a flat one.
-constexpr uint32_t kSmallTris = 64, kSmallLights = 16, kSmallMats = 16;
-template <bool SMALL>
-struct SmallSceneLds {
-    float4 tri[3 * kSmallTris];
-    float4 light[3 * kSmallLights];
-    MatHead mat[kSmallMats];
-};
-template <>
-struct SmallSceneLds<false> {};
-PT_HD bool scene_is_small(uint32_t n_tris, uint32_t n_emissive_tris, uint32_t n_materials) { return n_tris <= kSmallTris && n_emissive_tris <= kSmallLights && n_materials <= kSmallMats; }
-
 // One iteration of PathGuidingIntegrator::random_walk's loop body (mod.rs:139-278).
 template <int KINDS, bool SMALL>
 __global__ __launch_bounds__(kBlock, KINDS != 7 ? PT_GUIDED_DIFFUSE_WAVES : PT_SHADE_WAVES) void k_shade_guided(SceneDev sc, SdTreeDev tree, RenderParams rp, GuidedParams gp, PathCols in, HitCols hit, PathCols out,
@@ -842,12 +827,7 @@ __global__ __launch_bounds__(kBlock, KINDS != 7 ? PT_GUIDED_DIFFUSE_WAVES : PT_S
 #define PT_STAGE_HI (sm_stage_hi + (threadIdx.x / 64u) * 4u * 64u)
     PT_TICK_INIT();
     __shared__ SmallSceneLds<SMALL> sm_scene;
-    if constexpr (SMALL) {
-        for (uint32_t k = threadIdx.x; k < 3u * sc.n_tris; k += kBlock) sm_scene.tri[k] = sc.tri_v[k];
-        for (uint32_t k = threadIdx.x; k < 3u * sc.n_emissive_tris; k += kBlock) sm_scene.light[k] = sc.light_v[k];
-        for (uint32_t k = threadIdx.x; k < sc.n_materials; k += kBlock) sm_scene.mat[k] = MatHead{sc.materials[k].kind, sc.materials[k].roughness};
-        __syncthreads();
-    }
+    if constexpr (SMALL) stage_small_scene(sc, sm_scene);
     uint32_t n_shaded = 0, n_skipped = 0;
     const uint32_t n_bottom = cur->n_active;
     const uint32_t n = n_bottom + *cur_top;

@@ -404,15 +404,40 @@ __global__ __launch_bounds__(kBlock) void k_occluded_batch(SceneDev sc, const fl
     }
 }
 
+// Small scenes (the Cornell box: 24 triangles, 2 of them lights, 5 materials) keep their triangles, their light table and
+// their material heads in LDS for the shade kernels (SMALL): what this kernel is short of is the CU's vector-memory front
+// end — every 16-byte-per-lane load holds the address pipeline a good 16 cycles whatever it hits — and LDS is a second,
+// independent pipe. Same values from another place; a separate instantiation, so that no load becomes a flat one.
+constexpr uint32_t kSmallTris = 64, kSmallLights = 16, kSmallMats = 16;
+template <bool SMALL>
+struct SmallSceneLds {
+    float4 tri[3 * kSmallTris];
+    float4 light[3 * kSmallLights];
+    MatHead mat[kSmallMats];
+};
+template <>
+struct SmallSceneLds<false> {};
+PT_HD bool scene_is_small(uint32_t n_tris, uint32_t n_emissive_tris, uint32_t n_materials) { return n_tris <= kSmallTris && n_emissive_tris <= kSmallLights && n_materials <= kSmallMats; }
+
+template <class Lds>
+PT_D void stage_small_scene(const SceneDev& sc, Lds& sm) {  // every thread of the workgroup
+    for (uint32_t k = threadIdx.x; k < 3u * sc.n_tris; k += kBlock) sm.tri[k] = sc.tri_v[k];
+    for (uint32_t k = threadIdx.x; k < 3u * sc.n_emissive_tris; k += kBlock) sm.light[k] = sc.light_v[k];
+    for (uint32_t k = threadIdx.x; k < sc.n_materials; k += kBlock) sm.mat[k] = MatHead{sc.materials[k].kind, sc.materials[k].roughness};
+    __syncthreads();
+}
+
 // ------------------------------------------------------------------ shade: `path` integrator
 // One iteration of PathIntegrator::li's loop body after the intersection (path_tracer.rs:69-180).
-template <int KINDS>
+template <int KINDS, bool SMALL>
 __global__ __launch_bounds__(kBlock, KINDS != 7 ? PT_PATH_DIFFUSE_WAVES : PT_SHADE_WAVES) void k_shade_path(SceneDev sc, RenderParams rp, PathCols in, HitCols hit, PathCols out, ShadowCols sh,
                                                        const RoundCounters* cur, RoundCounters* nxt) {
     __shared__ BlockAlloc sm_alloc;
     __shared__ uint32_t sm_count;
     __shared__ BlockSort sm_sort;
     constexpr bool kSort = PT_SORT_SHADE && KINDS == 7;  // measured: a gain where conductors mix with other surfaces (veach-mis shade -9 %, veach-bidir -7 %), none or a loss on the Cornell box
+    __shared__ SmallSceneLds<SMALL> sm_scene;
+    if constexpr (SMALL) stage_small_scene(sc, sm_scene);
     uint32_t n_shaded = 0;
     const uint32_t n = cur->n_active;
     const uint32_t stride = gridDim.x * blockDim.x;
@@ -461,7 +486,9 @@ __global__ __launch_bounds__(kBlock, KINDS != 7 ? PT_PATH_DIFFUSE_WAVES : PT_SHA
                     pid = f2u(pp.w);
                     beta = load_spec(in.beta0, in.beta1, i);
                 }
-                const Surface sf = make_surface(sc, prim, tb.y, tb.z, tb.w);
+                Surface sf;
+                if constexpr (SMALL) sf = make_surface_from(sc, sm_scene.tri, prim, tb.y, tb.z, tb.w);
+                else sf = make_surface(sc, prim, tb.y, tb.z, tb.w);
                 const int material = tag_material(prim_tag.y);
                 uint32_t depth = flags & FLAG_DEPTH_MASK;
                 if (material < 0) {
@@ -476,7 +503,9 @@ __global__ __launch_bounds__(kBlock, KINDS != 7 ? PT_PATH_DIFFUSE_WAVES : PT_SHA
                     flags &= ~FLAG_PASS_MASK;
                     const V3 wo = -d;
                     const V3 p = surf_p(sf);
-                    const Bsdf bsdf = make_bsdf<KINDS>(sc, rp.spec, material, rp4.w);
+                    Bsdf bsdf;
+                    if constexpr (SMALL) bsdf = make_bsdf_head<KINDS>(rp.spec, sm_scene.mat[material], material, rp4.w);
+                    else bsdf = make_bsdf<KINDS>(sc, rp.spec, material, rp4.w);
                     const bool spec_bounce = (flags & FLAG_SPECULAR_BOUNCE) != 0;
                     // emitted radiance of the surface that was hit (path_tracer.rs:82-108)
                     if (sf.tri.mesh < sc.n_emissive_meshes) {
@@ -497,7 +526,10 @@ __global__ __launch_bounds__(kBlock, KINDS != 7 ? PT_PATH_DIFFUSE_WAVES : PT_SHA
                         Tri lt;
                         float pmf;
                         LiSample ls;
-                        if (choose_light(sc, u1d, lt, pmf) && light_sample_li(lt, p, ua, ub, ls)) {
+                        bool have_light;
+                        if constexpr (SMALL) have_light = choose_light_from(sc, sm_scene.light, u1d, lt, pmf);
+                        else have_light = choose_light(sc, u1d, lt, pmf);
+                        if (have_light && light_sample_li(lt, p, ua, ub, ls)) {
                             Spec f = bsdf_eval(bsdf, sf.frame, sf.ng, wo, ls.wl, true) / (ls.pdf * pmf);
                             if (!spec_is_black(f)) {
                                 const V3 lp = (ls.blo + ls.bhi) / 2.0f;
@@ -730,11 +762,13 @@ __global__ __launch_bounds__(kBlock) void k_raygen_light(SceneDev sc, CameraDev 
 
 // LightPathIntegrator::random_walk loop body (light_path_tracer.rs:74-118). The depth counter counts loop
 // iterations (a pass-through surface burns one, unlike `path`).
-template <int KINDS>
+template <int KINDS, bool SMALL>
 __global__ __launch_bounds__(kBlock, PT_SHADE_WAVES) void k_shade_light(SceneDev sc, CameraDev cam, RenderParams rp, PathCols in, HitCols hit, PathCols out, ShadowCols sh,
                                                         const RoundCounters* cur, RoundCounters* nxt) {
     __shared__ BlockAlloc sm_alloc;
     __shared__ uint32_t sm_count;
+    __shared__ SmallSceneLds<SMALL> sm_scene;
+    if constexpr (SMALL) stage_small_scene(sc, sm_scene);
     uint32_t n_shaded = 0;
     const uint32_t n = cur->n_active;
     const uint32_t stride = gridDim.x * blockDim.x;
@@ -757,7 +791,9 @@ __global__ __launch_bounds__(kBlock, PT_SHADE_WAVES) void k_shade_light(SceneDev
             const float4 tb = hit.tb[i];
             const Lambdas wl = load_lambdas(rp.lambda_tab, rp4.w, true);
             const uint2 prim_tag = hit.prim[i];
-            const Surface sf = make_surface(sc, prim_tag.x, tb.y, tb.z, tb.w);
+            Surface sf;
+            if constexpr (SMALL) sf = make_surface_from(sc, sm_scene.tri, prim_tag.x, tb.y, tb.z, tb.w);
+            else sf = make_surface(sc, prim_tag.x, tb.y, tb.z, tb.w);
             const int material = tag_material(prim_tag.y);
             uint32_t depth = (flags & FLAG_DEPTH_MASK) + 1;  // iterations consumed including this one
             if (material < 0) {
@@ -767,7 +803,9 @@ __global__ __launch_bounds__(kBlock, PT_SHADE_WAVES) void k_shade_light(SceneDev
                 shaded = true;
                 const V3 wo = -d;
                 const V3 p = surf_p(sf);
-                const Bsdf bsdf = make_bsdf<KINDS>(sc, rp.spec, material, rp4.w);
+                Bsdf bsdf;
+                if constexpr (SMALL) bsdf = make_bsdf_head<KINDS>(rp.spec, sm_scene.mat[material], material, rp4.w);
+                else bsdf = make_bsdf<KINDS>(sc, rp.spec, material, rp4.w);
                 CameraWi cw;
                 if (!bsdf_is_specular(bsdf) && camera_sample_wi(cam, p, cw)) {
                     Spec f = bsdf_eval(bsdf, sf.frame, sf.ng, wo, cw.wc, false) * spec_splat(cw.importance) * beta / cw.pdf;

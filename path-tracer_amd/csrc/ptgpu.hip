@@ -160,7 +160,7 @@ struct ptgpu_ctx {
     std::vector<hipEvent_t> ev_pool;
     std::vector<int> ev_stage;  // stage of pair i (events 2i, 2i+1)
     bool census_on = false;
-    int kinds = 7;       // material kinds in use, rounded up to a compiled set (PT_LAUNCH_BY_KINDS)
+    int kinds = 7;       // material kinds in use, rounded up to a compiled set (PT_LAUNCH_SHADE)
     std::map<const void*, int> resident_blocks;  // per shade kernel: workgroups resident per CU (resident_grid)
     size_t bvh_lds = 0;  // dynamic LDS bytes of every kernel that walks the BVH (pt_device.h: bvh_intersect), for the mode in use
     size_t bvh_lds_mode[2] = {0, 0};  // binary walk, wide walk
@@ -196,14 +196,26 @@ namespace {
 // kernel runs 3 + 3 + 2 otherwise: measured 3-4 % of the kernel on the Cornell box, 4 blocks per CU 17 % slower than 3).
 #define PT_LAUNCH_ONE_KIND(c, kernel, grid, ...)                                                                          \
     hipLaunchKernelGGL(kernel, dim3(resident_grid((c), (const void*)kernel, (grid))), dim3(kBlock), 0, (c)->stream, __VA_ARGS__)
-#define PT_LAUNCH_BY_KINDS(c, kernel, grid, ...)                                                                        \
-    do {                                                                                                                 \
-        if ((c)->kinds == 1) PT_LAUNCH_ONE_KIND(c, HIP_KERNEL_NAME(kernel<1>), grid, __VA_ARGS__);                       \
-        else if ((c)->kinds == 3) PT_LAUNCH_ONE_KIND(c, HIP_KERNEL_NAME(kernel<3>), grid, __VA_ARGS__);                  \
-        else PT_LAUNCH_ONE_KIND(c, HIP_KERNEL_NAME(kernel<7>), grid, __VA_ARGS__);                                       \
-    } while (0)
 
-int resident_grid(ptgpu_ctx* c, const void* kernel, int grid, size_t dynamic_lds = 0) {
+int resident_grid(ptgpu_ctx* c, const void* kernel, int grid, size_t dynamic_lds = 0);
+// A shade kernel by material-kind set and, where the scene is small enough, with the scene in LDS (pt_kernels.h: SmallSceneLds)
+#define PT_LAUNCH_SHADE_S(c, kernel, SMALL, grid, ...)                                    \
+    do {                                                                                   \
+        auto k1_ = kernel<1, SMALL>;                                                       \
+        auto k3_ = kernel<3, SMALL>;                                                       \
+        auto k7_ = kernel<7, SMALL>;                                                       \
+        if ((c)->kinds == 1) PT_LAUNCH_ONE_KIND(c, k1_, grid, __VA_ARGS__);                \
+        else if ((c)->kinds == 3) PT_LAUNCH_ONE_KIND(c, k3_, grid, __VA_ARGS__);           \
+        else PT_LAUNCH_ONE_KIND(c, k7_, grid, __VA_ARGS__);                                \
+    } while (0)
+#define PT_LAUNCH_SHADE(c, kernel, grid, ...)                                                                                \
+    do {                                                                                                                      \
+        static const bool no_small = getenv("PTGPU_NO_SMALL_SCENE") != nullptr; /* A/B */                                     \
+        if (!no_small && scene_is_small((c)->scene.n_tris, (c)->scene.n_emissive_tris, (c)->scene.n_materials))               \
+            PT_LAUNCH_SHADE_S(c, kernel, true, grid, __VA_ARGS__);                                                            \
+        else PT_LAUNCH_SHADE_S(c, kernel, false, grid, __VA_ARGS__);                                                          \
+    } while (0)
+int resident_grid(ptgpu_ctx* c, const void* kernel, int grid, size_t dynamic_lds) {
     auto it = c->resident_blocks.find(kernel);
     if (it == c->resident_blocks.end()) {
         int per_cu = 0;
@@ -988,9 +1000,9 @@ int run_batch_path_like(ptgpu_ctx* c, bool light, const RenderParams& rp, uint32
         {
             StageTimer t(c, PTGPU_STAGE_SHADE);
             if (light)
-                PT_LAUNCH_BY_KINDS(c, k_shade_light, grid, c->scene, c->camera, rp, A, H, B, S, cnt + round, cnt + round + 1);
+                PT_LAUNCH_SHADE(c, k_shade_light, grid, c->scene, c->camera, rp, A, H, B, S, cnt + round, cnt + round + 1);
             else
-                PT_LAUNCH_BY_KINDS(c, k_shade_path, grid, c->scene, rp, A, H, B, S, cnt + round, cnt + round + 1);
+                PT_LAUNCH_SHADE(c, k_shade_path, grid, c->scene, rp, A, H, B, S, cnt + round, cnt + round + 1);
         }
         {
             StageTimer t(c, PTGPU_STAGE_OCCLUDE);
