@@ -177,6 +177,8 @@ typedef struct ptgpu_sdtree_info {
     uint32_t iteration;      /* Guider::iteration of the resident sampling tree */
     uint32_t refined_ahead;  /* 1 after ptgpu_guided_refine until the next ptgpu_guided_wave */
     float bounds[6];         /* STree::bounds (stree.rs:28-31): min.xyz, max.xyz */
+    uint32_t refine_repeats; /* refinements of this render that were built twice: the new generation outgrew a buffer sized
+                              * before its counts were known (the spatial sweep runs on the device) */
 } ptgpu_sdtree_info;
 int ptgpu_guided_tree_info(ptgpu_ctx* ctx, ptgpu_sdtree_info* out);
 /* Any pointer may be NULL. spatial: 4 words per STree node {left, right, split_axis, leaf id | 0xffffffff for interior};

@@ -74,7 +74,7 @@ class Stats(C.Structure):
 
 class SdTreeInfo(C.Structure):
     _fields_ = [("n_spatial_nodes", C.c_uint32), ("n_leaves", C.c_uint32), ("n_sampling_nodes", C.c_uint32), ("n_collector_nodes", C.c_uint32),
-                ("iteration", C.c_uint32), ("refined_ahead", C.c_uint32), ("bounds", C.c_float * 6)]
+                ("iteration", C.c_uint32), ("refined_ahead", C.c_uint32), ("bounds", C.c_float * 6), ("refine_repeats", C.c_uint32)]
 
 
 class Hit(C.Structure):
@@ -525,7 +525,7 @@ class Context:
         """The resident SD-tree as a dict of numpy arrays (layout: ptgpu_guided_tree_download in include/ptgpu.h)."""
         info = SdTreeInfo()
         self._check(self.lib.ptgpu_guided_tree_info(self.handle, C.byref(info)))
-        t = {"iteration": info.iteration, "bounds": np.array(list(info.bounds), dtype=np.float32),
+        t = {"iteration": info.iteration, "refine_repeats": info.refine_repeats, "bounds": np.array(list(info.bounds), dtype=np.float32),
              "spatial": np.zeros((info.n_spatial_nodes, 4), dtype=np.uint32), "leaf": np.zeros((info.n_leaves, 5), dtype=np.uint32),
              "s_rad": np.zeros((info.n_sampling_nodes, 4), dtype=np.float32), "s_child": np.zeros((info.n_sampling_nodes, 4), dtype=np.uint16),
              "s_weight": np.zeros(info.n_leaves, dtype=np.float32),

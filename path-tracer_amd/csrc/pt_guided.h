@@ -85,7 +85,7 @@ static_assert(sizeof(SNode2) == 128, "one line");
 
 struct SdTreeDev {
     const uint4* snodes;
-    const uint2* top;  // {entry, sampler word of the leaf}: jump table over the first kStreeTopLevels decisions (sdtree_host.h)
+    const uint2* top;  // {entry, sampler word of the leaf}: jump table over the first kStreeTopLevels decisions (pt_refine.h: k_build_top)
     const uint4* leaf_info;
     const SNode* s_node;  // sampling arena: a node's four child sums and four child links in one 32-byte record (one line per level)
     const SNode2* s_node2;  // the same trees, two levels per 128-byte record (PT_TWO_LEVEL)

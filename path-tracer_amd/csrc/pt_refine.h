@@ -1,10 +1,10 @@
-// pt_refine.h — the directional half of STree::new_iteration on the device (stree.rs:42-54,255-260; dtree.rs:185-198,
+// pt_refine.h — STree::new_iteration on the device (stree.rs:42-101,255-260; dtree.rs:185-198,
 // 291-328). Between two waves every spatial leaf's collector quadtree is (1) summed bottom-up (DTree::build), (2) copied
 // into the sampling arena the next wave reads (emit_into), (3) reshaped by subdivide_and_clear. The collector sums
 // already live in HBM (the record pass splatted them there, RCCL all-reduced them in place), so doing this here removes
-// the round trip of the whole tree over PCIe and the host pass over it; the host keeps only the spatial binary tree
-// (a few 10^4 nodes), decides its splits from the per-leaf weights, and tells the device which old leaf every new
-// leaf descends from. One thread per leaf: the trees are small (~10^2 nodes) and there are 10^4..10^5 of them.
+// the round trip of the whole tree over PCIe and the host pass over it. The spatial binary tree is refined here as well
+// (second half of this file): the host only reads four totals per refinement to size the next collector.
+// One thread (or one wave) per leaf: the trees are small (~10^2 nodes) and there are 10^4..10^5 of them.
 // The arithmetic (sum order, IEEE division, 0.25^depth) is the host's/reference's, so the decisions are the same bits;
 // only the numbering of quadtree nodes inside a leaf differs (breadth of the walk here, free-list order there), which
 // nothing observes.
@@ -13,6 +13,11 @@
 
 namespace pt {
 
+// What the refinement tells the host at its one synchronisation (device words; see the spatial refinement below).
+enum StreeHeader : uint32_t {
+    kHdrNodes = 0, kHdrLeaves = 1, kHdrArenaLo = 2, kHdrArenaHi = 3, kHdrLevels = 4, kHdrFlags = 5, kHdrCollector = 6, kHdrRefineError = 7, kHdrWords = 8
+};
+enum StreeFlags : uint32_t { kStreeTooDeep = 1u, kStreeNodesOver = 2u, kStreeLeavesOver = 4u, kStreeArenaOver = 8u, kStreeArenaBeyondU32 = 16u };
 struct RefineArgs {
     // the generation just trained
     const uint2* old_child;     // collector topology
@@ -26,6 +31,7 @@ struct RefineArgs {
     const uint32_t* halvings;   // per new leaf: how many spatial splits lie between (collector weight / 2^k)
     const uint32_t* s_off;      // per new leaf: first node in the sampling arena (prefix of old sizes, host)
     uint32_t n_new_leaves;
+    const uint32_t* header;     // when set (before the host knows the counts): n_new_leaves = header[kHdrLeaves], nothing runs if header[kHdrFlags] (see the spatial refinement below)
     SNode* s_node;              // sampling arena
     uint32_t* new_size;         // per new leaf: node count of the reshaped collector
     const uint32_t* new_off;    // per new leaf: first node (exclusive scan of new_size)
@@ -37,6 +43,7 @@ struct RefineArgs {
 };
 
 PT_D float sum4(float4 r) { return (((0.0f + r.x) + r.y) + r.z) + r.w; }
+PT_D uint32_t refine_new_leaves(const RefineArgs& a) { return !a.header ? a.n_new_leaves : a.header[kHdrFlags] ? 0u : a.header[kHdrLeaves]; }
 
 // The per-leaf kernels below run ONE WAVE per spatial leaf (four leaves per workgroup): the walk over a leaf's quadtree
 // is serial (one lane does it), but every step of it used to be a round trip to global memory (~120 dependent steps, 0.15-0.2
@@ -165,7 +172,7 @@ template <uint32_t LANES>
 __global__ __launch_bounds__(kBlock) void k_refine_emit_count(RefineArgs a) {
     __shared__ LeafWalkLds sm[LANES == 64u ? kLeavesPerBlock : 1u];
     const uint32_t leaf = LANES == 64u ? blockIdx.x * kLeavesPerBlock + threadIdx.x / 64u : blockIdx.x * kBlock + threadIdx.x, lane = LANES == 64u ? __lane_id() : 0u;
-    if (leaf >= a.n_new_leaves) return;
+    if (leaf >= refine_new_leaves(a)) return;
     LeafTreeLds& t = sm[LANES == 64u ? threadIdx.x / 64u : 0u].tree;
     ReshapeItem* lds_stack = sm[LANES == 64u ? threadIdx.x / 64u : 0u].stack;
     const uint32_t src = a.src_leaf[leaf];
@@ -199,7 +206,7 @@ template <uint32_t LANES>
 __global__ __launch_bounds__(kBlock) void k_refine_write(RefineArgs a) {
     __shared__ LeafWalkLds sm[LANES == 64u ? kLeavesPerBlock : 1u];
     const uint32_t leaf = LANES == 64u ? blockIdx.x * kLeavesPerBlock + threadIdx.x / 64u : blockIdx.x * kBlock + threadIdx.x, lane = LANES == 64u ? __lane_id() : 0u;
-    if (leaf >= a.n_new_leaves) return;
+    if (leaf >= refine_new_leaves(a)) return;
     LeafTreeLds& t = sm[LANES == 64u ? threadIdx.x / 64u : 0u].tree;
     ReshapeItem* lds_stack = sm[LANES == 64u ? threadIdx.x / 64u : 0u].stack;
     const uint32_t src = a.src_leaf[leaf];
@@ -246,6 +253,190 @@ __global__ __launch_bounds__(1024) void k_exclusive_scan(const uint32_t* in, uin
     if (t == 1023u) out[n] = sm[1023];
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The spatial half of STree::new_iteration on the device: STree::subdivide_nodes (stree.rs:55-101), the numbering of
+// the new leaves and the layout of the next sampling arena. The reference sweeps the node array once, front to back;
+// a leaf heavier than the threshold gets two children APPENDED (copies of it with half its weight), and the sweep
+// reaches them later and may split them again. In closed form: an old leaf of weight w ends up as a complete subtree of
+// depth h = the number of halvings that bring w under the threshold (all nodes of one level of it weigh the same, so
+// they split together), and the append order is level by level — first the level-1 children of every splitting old
+// leaf in old node order, then all level-2 nodes in the order of their parents, and so on. So the first node of leaf
+// i's level-L block sits at n_old + the exclusive scan, over (L, i) in that order, of the block sizes 2^L.
+//   k_stree_plan      per old node: h, its block sizes per level, and the totals (nodes, leaves, sampling-arena nodes)
+//   k_exclusive_scan_levels over the block sizes of the levels in use
+//   k_stree_append    writes the new node array (old nodes, now interior where they split, then the blocks) and, per
+//                     node, whether it is a leaf and the size of the sampling copy it will need
+//   k_exclusive_scan_dev (twice) -> leaf ids in node order (the reference's numbering) and arena offsets
+//   k_stree_finalize  leaf words of the node array, src_leaf / halvings / s_off per new leaf
+// The host learns the four totals at the one synchronisation of the refinement; until then kernels read them from the
+// header and buffers are sized by capacity (exceeding one sets a flag, nothing is written, the host grows and repeats).
+constexpr uint32_t kMaxSpatialHalvings = 20;  // a leaf may split into 2^20 in one refinement; beyond is an error (the reference would sweep as long)
+struct StreeArgs {
+    const uint4* old_nodes;     // {left, right, axis, -} / leaves {0, sampler word, axis, leaf id}
+    uint32_t n_old_nodes;
+    const float* old_weight;    // per old leaf: the collector's statistical weight
+    const uint32_t* old_size;   // per old leaf: collector node count (= the size of a sampling copy of it)
+    float threshold;            // spatial threshold * sqrt(2^iteration)
+    uint32_t* halvings_of;      // per old node
+    uint32_t* blocks;           // [kMaxSpatialHalvings][n_old_nodes]: nodes of level L + 1 under old node i
+    uint32_t* block_start;      // exclusive scan of the above over the levels in use
+    uint4* new_nodes;
+    uint2* origin;              // per new node: {old leaf, halvings} (leaves)
+    uint32_t* is_leaf;          // per new node (+ 1: scan total)
+    uint32_t* copy_size;        // per new node (+ 1)
+    uint32_t* leaf_rank;        // exclusive scans of the two above
+    uint32_t* copy_start;
+    uint32_t* src_leaf;         // per new leaf (RefineArgs)
+    uint32_t* halvings;
+    uint32_t* s_off;
+    uint32_t* header;           // StreeHeader
+    uint32_t cap_nodes, cap_leaves;
+    uint64_t cap_arena;
+};
+
+__global__ __launch_bounds__(kBlock) void k_stree_plan(StreeArgs a) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t h = 0, nodes = 0, leaves = 0;
+    unsigned long long arena = 0;
+    if (i < a.n_old_nodes) {
+        const uint4 n = a.old_nodes[i];
+        nodes = 1;
+        if (n.x == 0u) {
+            float w = a.old_weight[n.w];
+            while (w > a.threshold && h <= kMaxSpatialHalvings) {  // subdivide_nodes: split while heavier than the threshold, children weigh half
+                w /= 2.0f;
+                h++;
+            }
+            if (h > kMaxSpatialHalvings) {
+                atomicOr(a.header + kHdrFlags, (uint32_t)kStreeTooDeep);
+                h = kMaxSpatialHalvings;
+            }
+            nodes += (2u << h) - 2u;
+            leaves = 1u << h;
+            arena = (unsigned long long)leaves * a.old_size[n.w];
+        }
+        a.halvings_of[i] = h;
+        for (uint32_t l = 0; l < kMaxSpatialHalvings; l++) a.blocks[(size_t)l * a.n_old_nodes + i] = h > l ? 2u << l : 0u;
+    }
+    // totals: one atomic per wave and word
+    uint32_t hmax = h;
+    for (int off = 32; off > 0; off >>= 1) {
+        nodes += (uint32_t)__shfl_xor((int)nodes, off);
+        leaves += (uint32_t)__shfl_xor((int)leaves, off);
+        arena += ((unsigned long long)(uint32_t)__shfl_xor((int)(arena >> 32), off) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)arena, off);
+        hmax = max(hmax, (uint32_t)__shfl_xor((int)hmax, off));
+    }
+    if (__lane_id() == 0 && nodes != 0u) {
+        atomicAdd(a.header + kHdrNodes, nodes);
+        atomicAdd(a.header + kHdrLeaves, leaves);
+        atomicAdd(reinterpret_cast<unsigned long long*>(a.header + kHdrArenaLo), arena);
+        atomicMax(a.header + kHdrLevels, hmax);
+    }
+}
+
+// The scans of the spatial refinement: as k_exclusive_scan, with the element count read from the header (the host does
+// not know it yet). n = min(header[word] * per, cap); the total also goes to *total_out when given.
+__global__ __launch_bounds__(1024) void k_exclusive_scan_dev(const uint32_t* in, uint32_t* out, const uint32_t* header, uint32_t word, uint32_t per_unit, uint32_t cap, uint32_t* total_out) {
+    __shared__ uint32_t sm[1024];
+    const unsigned long long want = (unsigned long long)header[word] * per_unit;
+    const uint32_t n = want < cap ? (uint32_t)want : cap;
+    const uint32_t t = threadIdx.x, per = (n + 1023u) / 1024u;
+    const uint32_t lo = t * per < n ? t * per : n, hi = lo + per < n ? lo + per : n;
+    uint32_t s = 0;
+    for (uint32_t i = lo; i < hi; i++) s += in[i];
+    sm[t] = s;
+    __syncthreads();
+    for (uint32_t off = 1; off < 1024u; off <<= 1) {
+        const uint32_t v = t >= off ? sm[t - off] : 0u;
+        __syncthreads();
+        sm[t] += v;
+        __syncthreads();
+    }
+    uint32_t run = sm[t] - s;
+    for (uint32_t i = lo; i < hi; i++) {
+        out[i] = run;
+        run += in[i];
+    }
+    if (t == 1023u) {
+        out[n] = sm[1023];
+        if (total_out) *total_out = sm[1023];
+    }
+}
+
+PT_D bool stree_fits(const StreeArgs& a) {
+    const unsigned long long arena = ((unsigned long long)a.header[kHdrArenaHi] << 32) | a.header[kHdrArenaLo];
+    return (a.header[kHdrFlags] & kStreeTooDeep) == 0u && a.header[kHdrNodes] <= a.cap_nodes && a.header[kHdrLeaves] <= a.cap_leaves && arena <= a.cap_arena &&
+           arena <= 0xfffffff0ull;
+}
+
+// One thread per (level, old node): level 0 is the old node itself, level L >= 1 its block of 2^L appended nodes.
+__global__ __launch_bounds__(kBlock) void k_stree_append(StreeArgs a) {
+    const uint32_t levels = a.header[kHdrLevels];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {  // the capacity verdict, once
+        const unsigned long long arena = ((unsigned long long)a.header[kHdrArenaHi] << 32) | a.header[kHdrArenaLo];
+        uint32_t f = 0;
+        if (a.header[kHdrNodes] > a.cap_nodes) f |= kStreeNodesOver;
+        if (a.header[kHdrLeaves] > a.cap_leaves) f |= kStreeLeavesOver;
+        if (arena > a.cap_arena) f |= kStreeArenaOver;
+        if (arena > 0xfffffff0ull) f |= kStreeArenaBeyondU32;
+        if (f) atomicOr(a.header + kHdrFlags, f);
+    }
+    if (!stree_fits(a)) return;
+    const unsigned long long item = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t level = (uint32_t)(item / a.n_old_nodes), i = (uint32_t)(item % a.n_old_nodes);
+    if (level > levels) return;
+    const uint4 n = a.old_nodes[i];
+    const uint32_t h = a.halvings_of[i];
+    const auto start_of = [&](uint32_t l) { return a.n_old_nodes + a.block_start[(size_t)(l - 1u) * a.n_old_nodes + i]; };  // first node of leaf i's level-l block
+    if (level == 0u) {
+        if (n.x != 0u) {
+            a.new_nodes[i] = make_uint4(n.x, n.y, n.z, 0xffffffffu);
+            a.is_leaf[i] = 0u;
+            a.copy_size[i] = 0u;
+        } else if (h == 0u) {
+            a.new_nodes[i] = make_uint4(0u, 0u, n.z, 0u);
+            a.origin[i] = make_uint2(n.w, 0u);
+            a.is_leaf[i] = 1u;
+            a.copy_size[i] = a.old_size[n.w];
+        } else {
+            const uint32_t c = start_of(1u);
+            a.new_nodes[i] = make_uint4(c, c + 1u, n.z, 0xffffffffu);
+            a.is_leaf[i] = 0u;
+            a.copy_size[i] = 0u;
+        }
+        return;
+    }
+    if (n.x != 0u || h < level) return;
+    const uint32_t base = start_of(level), axis = (n.z + level) % 3u, size = a.old_size[n.w];
+    const uint32_t below = h > level ? start_of(level + 1u) : 0u;
+    for (uint32_t t = 0; t < (1u << level); t++) {
+        const uint32_t idx = base + t;
+        if (h > level) {
+            a.new_nodes[idx] = make_uint4(below + 2u * t, below + 2u * t + 1u, axis, 0xffffffffu);
+            a.is_leaf[idx] = 0u;
+            a.copy_size[idx] = 0u;
+        } else {
+            a.new_nodes[idx] = make_uint4(0u, 0u, axis, 0u);
+            a.origin[idx] = make_uint2(n.w, level);
+            a.is_leaf[idx] = 1u;
+            a.copy_size[idx] = size;
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_stree_finalize(StreeArgs a) {
+    if (a.header[kHdrFlags]) return;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.header[kHdrNodes] || !a.is_leaf[i]) return;
+    const uint32_t id = a.leaf_rank[i], off = a.copy_start[i];
+    const uint2 o = a.origin[i];
+    a.new_nodes[i].y = off;  // (the zero-mean bit comes from k_refine_patch_words)
+    a.new_nodes[i].w = id;
+    a.src_leaf[id] = o.x;
+    a.halvings[id] = o.y;
+    a.s_off[id] = off;
+}
+
 // The descent hands the leaf's sampler word (sampling-arena offset | mean_is_zero << 31) out of the spatial nodes and
 // the jump table; the host filled in the offsets, the zero-mean bits are known only here.
 __global__ __launch_bounds__(kBlock) void k_refine_patch_words(const uint4* leaf_info, uint4* snodes, uint32_t n_snodes, uint2* top, uint32_t n_top) {
@@ -264,9 +455,10 @@ __global__ __launch_bounds__(kBlock) void k_refine_patch_words(const uint4* leaf
 // (one bit per decision, first decision in the top bit) names where that prefix of decisions ends: a leaf reached
 // after `depth` <= kStreeTopLevels steps — {1 << 31 | leaf << 5 | depth, the leaf's sampler word} — or the interior node
 // standing at depth kStreeTopLevels — {node << 5 | depth, 0}. One thread per entry follows the node links.
-__global__ __launch_bounds__(kBlock) void k_build_top(const uint4* snodes, uint2* top) {
+__global__ __launch_bounds__(kBlock) void k_build_top(const uint4* snodes, uint2* top, const uint32_t* header) {
     const uint32_t code = blockIdx.x * blockDim.x + threadIdx.x;
     if (code >= (1u << kStreeTopLevels)) return;
+    if (header && header[kHdrFlags]) return;  // the node array was not written (it did not fit: the host grows it and repeats)
     uint32_t ni = 0, depth = 0;
     for (;;) {
         const uint4 n = snodes[ni];

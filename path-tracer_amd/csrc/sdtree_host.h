@@ -1,7 +1,9 @@
-// sdtree_host.h — host side of the guided integrator's SD-tree (Müller et al.). The directional quadtrees live and are
-// refined on the device (pt_refine.h); the host keeps the spatial binary tree: between waves it learns each leaf's
-// statistical weight, runs STree::subdivide_nodes (pt/src/integrator/path_guiding/stree.rs:55-101) on the weights,
-// renumbers the leaves, lays out the next sampling arena and builds the jump table of the spatial descents.
+// sdtree_host.h — host side of the guided integrator's SD-tree (Müller et al.). The whole tree lives and is refined on
+// the device (pt_refine.h: the spatial sweep in closed form, the directional quadtrees per leaf); the host keeps the
+// tree's bounds, builds the one-node tree of wave 0, and holds the reference's spatial sweep AS WRITTEN —
+// STree::subdivide_nodes (pt/src/integrator/path_guiding/stree.rs:55-101), a loop that appends children and meets them
+// again — as the yardstick the device's result is compared with word by word under PTGPU_CHECK_STREE (a test switch:
+// the weights come down for it alone).
 #pragma once
 #include <cstdint>
 #include <vector>

@@ -117,6 +117,37 @@ def test_sdtree_lookups_and_refinement_match_oracle_on_the_same_tree(gpu_ctx, na
     assert gpu_ctx.guard_counts() == guards_before   # no documented safety limit was hit
 
 
+@pytest.mark.parametrize("tiny_capacities", [False, True])
+def test_spatial_refinement_on_the_device_equals_the_sweep_as_written(gpu_ctx, tiny_capacities, monkeypatch):
+    """STree::subdivide_nodes, the leaf numbering and the arena offsets (stree.rs:55-101) run on the device in closed form
+    (pt_refine.h: k_stree_*). With PTGPU_CHECK_STREE the library also runs the reference's sweep as written (a loop over
+    the node array that appends children and meets them again) on the host after every wave, over the same weights, and
+    fails the wave unless every node word, leaf origin and arena offset is equal. A low spatial threshold makes leaves
+    split several levels at once (the first refinement turns one leaf into hundreds). With PTGPU_STREE_CAP_TEST the
+    buffers that are sized before the counts are known start tiny: the generation does not fit, is detected on the
+    device without a write out of bounds, and is built again after the host has grown them."""
+    monkeypatch.setenv("PTGPU_CHECK_STREE", "1")
+    if tiny_capacities:
+        monkeypatch.setenv("PTGPU_STREE_CAP_TEST", "1")
+    sc = pt.LoadedScene("cornell-box-guided", resx=96, resy=96, max_depth=8, integrator="guided")
+    gpu_ctx.load(sc)
+    integ = pt.IntegratorDesc.from_buffer_copy(sc.integrator)
+    integ.spatial_threshold = 40.0
+    n_waves = gpu_ctx.guided_begin(integ, 127)
+    nodes = []
+    for w in range(n_waves):
+        gpu_ctx.guided_wave(w)       # raises if the device's tree differs from the host sweep's
+        t = gpu_ctx.guided_tree()
+        nodes.append(len(t["spatial"]))
+        leaves = t["spatial"][t["spatial"][:, 0] == 0]
+        assert (np.sort(leaves[:, 3]) == np.arange(len(t["leaf"]))).all()          # every leaf numbered once
+        assert (leaves[:, 3] == np.arange(len(leaves))).all()                      # ... in node order (the reference's numbering)
+    repeats = gpu_ctx.guided_tree()["refine_repeats"]
+    gpu_ctx.guided_end()
+    assert nodes[0] == 1 and nodes[1] > 255 and nodes[-1] > nodes[1]               # one leaf -> hundreds in one refinement, then growth
+    assert (repeats > 0) == tiny_capacities
+
+
 @pytest.mark.parametrize("direct", [False, True])
 def test_sdtree_record_batch_matches_oracle(gpu_ctx, direct, monkeypatch):
     """(ii), then (iii) on the statistics the batch left. `direct` = the per-record splat (PTGPU_DIRECT_SPLAT) instead of
