@@ -15,6 +15,7 @@
 #include "cie_data.inc"
 #include "pt_guided.h"
 #include "pt_kernels.h"
+#include "pt_pinned.h"
 
 using namespace pt;
 
@@ -144,7 +145,7 @@ struct ptgpu_ctx {
     DevBuf<float4> d_shadow;  // q0 | q1 | q2,q3 contiguous (4 * capacity)
     DevBuf<RoundCounters> d_counters;
     DevBuf<uint32_t> d_top_counters;  // per round: entries queued from the top of the state set (guided: predicted-specular survivors)
-    std::vector<uint32_t> h_top_counters;
+    PinnedVec<uint32_t> h_top_counters;  // (page-locked, like h_counters: the host's looks at the queue length wait for these copies)
     DevBuf<double> d_film;         // kFilmStride doubles per pixel, film_copies films back to back
     uint32_t film_copies = 1;
     DevBuf<double> d_film_packed;  // RGB, what the ABI returns
@@ -153,7 +154,7 @@ struct ptgpu_ctx {
     SpecTab spec{nullptr, 0, 0};
     uint32_t n_materials = 0, n_emissions = 0;  // entries of the device materials / emissions arrays
     DevBuf<float4> d_lambda_tab;  // 4 float4 per table entry: lambdas, pdfs
-    std::vector<RoundCounters> h_counters;
+    PinnedVec<RoundCounters> h_counters;
     bool profiling = false;
     // HIP-event pool: each launch records a start/stop pair on the library's stream without waiting; the pairs are
     // resolved once per render call, so profiling does not serialise the host with the device.
