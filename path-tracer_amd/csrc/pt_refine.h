@@ -55,7 +55,7 @@ PT_D uint32_t refine_new_leaves(const RefineArgs& a) { return !a.header ? a.n_ne
 // thread per leaf, at 4 418 / 6 312 / 8 814 / 11 881 / 15 833 leaves): sums 24-52 against 176-193 (a thread's walk is
 // ~120 dependent round trips to memory however few the leaves); lazy push 37-75 against 36-257; sampling copy + count
 // 142 / 165 / 208 / 253 against 253 / 249 / 272 / 271; reshape + write 140 / 170 / 222 / 273 against 158 / 158 / 162 / 182.
-constexpr uint32_t kSumsWavePerLeafUpTo = 49152, kEmitWavePerLeafUpTo = 16384, kWriteWavePerLeafUpTo = 7168;
+constexpr uint32_t kSumsWavePerLeafUpTo = 49152, kEmitWavePerLeafUpTo = 1u << 22, kWriteWavePerLeafUpTo = 1u << 22;  // (the reshape is wave-parallel since round 3: reshape_collector_wave)
 constexpr uint32_t kLeafTreeLds = 256;
 constexpr uint32_t kLeavesPerBlock = kBlock / 64u;
 struct ReshapeItem {  // walk stack of reshape_collector
@@ -68,9 +68,17 @@ struct LeafTreeLds {
     float4 rad[kLeafTreeLds];
     uint2 child[kLeafTreeLds];
 };
-struct LeafWalkLds {  // k_refine_emit_count / k_refine_write, one wave per leaf: the tree and the walk's stack (private
-    LeafTreeLds tree;  // memory otherwise: 1 KB per lane of scratch, each push and pop a trip to memory)
-    ReshapeItem stack[kReshapeStack];
+struct ReshapeWaveLds {                // reshape_collector_wave's per-node results
+    uint8_t depth[kLeafTreeLds];       // item depth of a node that survives (root: 1), 0 = dropped with its subtree
+    uint16_t out_index[kLeafTreeLds];  // its index in the reshaped tree
+    uint16_t spawn_at[kLeafTreeLds];   // where the nodes spawned by its split cells start, behind the surviving nodes
+};
+struct LeafWalkLds {  // k_refine_emit_count / k_refine_write, one wave per leaf: the tree and, for the serial walk, its stack
+    LeafTreeLds tree;  // (private memory otherwise: 1 KB per lane of scratch, each push and pop a trip to memory)
+    union {
+        ReshapeItem stack[kReshapeStack];
+        ReshapeWaveLds par;
+    };
 };
 PT_D void wave_sync_lds() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }  // LDS traffic of one wave is in order; this keeps the compiler in line too
 
@@ -106,8 +114,28 @@ __global__ __launch_bounds__(kBlock) void k_refine_sums(RefineArgs a) {
             t.child[i] = a.old_child[base + i];
         }
         wave_sync_lds();
-        if (lane == 0) sweep(t.rad, t.child);
-        wave_sync_lds();
+        // the whole wave: every node takes its interior children's sums again until nothing changes (as many passes as
+        // the tree is deep; the terms and their order per node are the sweep's, so are the bits)
+        for (;;) {
+            bool changed = false;
+            for (uint32_t i = lane; i < n; i += LANES) {
+                const uint2 links = t.child[i];
+                if ((links.x | links.y) == 0u) continue;
+                float4 r = t.rad[i];
+                const float4 was = r;
+                const uint32_t l0 = child_link(links, 0), l1 = child_link(links, 1), l2 = child_link(links, 2), l3 = child_link(links, 3);
+                if (l0 > i && l0 < n) r.x = sum4(t.rad[l0]);
+                if (l1 > i && l1 < n) r.y = sum4(t.rad[l1]);
+                if (l2 > i && l2 < n) r.z = sum4(t.rad[l2]);
+                if (l3 > i && l3 < n) r.w = sum4(t.rad[l3]);
+                if (f2u(r.x) != f2u(was.x) || f2u(r.y) != f2u(was.y) || f2u(r.z) != f2u(was.z) || f2u(r.w) != f2u(was.w)) {
+                    t.rad[i] = r;
+                    changed = true;
+                }
+            }
+            wave_sync_lds();
+            if (!__any(changed)) break;
+        }
         for (uint32_t i = lane; i < n; i += LANES) a.old_rad[base + i] = t.rad[i];
     } else if (lane == 0)
         sweep(a.old_rad + base, a.old_child + base);
@@ -167,6 +195,150 @@ PT_D uint32_t reshape_collector(const RefineArgs& a, const float4* src_rad, cons
     return counter;
 }
 
+// The same for a tree staged in LDS, by the WHOLE wave. The serial walk above is ~100 steps of ~150 dependent instructions
+// on one lane — 35 us per leaf however small the tree, 0.2-0.3 ms per kernel and wave of the render, a constant every rank
+// of a multi-GPU job pays. Nothing in it is sequential but the numbering: whether a node survives depends on its ancestors'
+// decisions only (propagated top-down, one level per pass: children have larger indices than parents, each node one
+// parent), what a split cell spawns is a closed form (a cell of fraction f examined at depth d becomes a complete 4-ary
+// subtree with a level j wherever f / 4^j >= threshold and d + j < kMaxQuadLevel — exact: dividing by four commutes with
+// the rounding of f / total), and any numbering that keeps children behind their parents will do (surviving nodes in
+// their old order, spawned subtrees behind them, level by level). Same decisions, hence the same tree up to numbering.
+PT_D uint32_t spawned_by_cell(float value, float total, float threshold, uint32_t depth, uint32_t& levels, uint32_t& too_deep) {
+    uint32_t nodes = 0, width = 1;
+    levels = 0;
+    for (uint32_t d = depth;; d++) {
+        float frac;
+        if (total > 0.0f) frac = value / total;
+        else {
+            frac = 1.0f;
+            for (uint32_t k = 0; k < d; k++) frac *= 0.25f;
+        }
+        if (frac < threshold) break;
+        if (d >= kMaxQuadLevel) {
+            too_deep += width;
+            break;
+        }
+        nodes += width;
+        levels++;
+        if (nodes > 70000u) break;  // (a NaN fraction is "not below the threshold" all the way down: beyond the u16 links, an error either way)
+        width *= 4u;
+        value = value / 4.0f;
+    }
+    return nodes;
+}
+template <bool WRITE>
+PT_D uint32_t reshape_collector_wave(const RefineArgs& a, const LeafTreeLds& t, ReshapeWaveLds& w, uint32_t n, uint32_t new_base) {
+    const uint32_t lane = __lane_id();
+    const float total = sum4(t.rad[0]);
+    const auto frac_of = [&](float v, uint32_t depth) {
+        if (total > 0.0f) return v / total;
+        float f = 1.0f;
+        for (uint32_t k = 0; k < depth; k++) f *= 0.25f;
+        return f;
+    };
+    // (1) who survives, and at which depth
+    for (uint32_t i = lane; i < n; i += 64u) w.depth[i] = i == 0u ? 1u : 0u;
+    wave_sync_lds();
+    uint32_t expanded = 0, too_deep = 0;
+    for (;;) {
+        bool any = false;
+        for (uint32_t k = 0; k < kLeafTreeLds / 64u; k++) {
+            const uint32_t i = k * 64u + lane;
+            if (i >= n || ((expanded >> k) & 1u)) continue;
+            const uint32_t d = w.depth[i];
+            if (d == 0u) continue;
+            expanded |= 1u << k;
+            any = true;
+            const float4 v = t.rad[i];
+            const uint2 links = t.child[i];
+            const float r[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const uint32_t link = child_link(links, c);
+                if (link == 0u || link >= n) continue;
+                if (frac_of(r[c], d) < a.threshold) continue;
+                if (d >= kMaxQuadLevel) too_deep++;
+                else w.depth[link] = (uint8_t)(d + 1u);
+            }
+        }
+        wave_sync_lds();
+        if (!__any(any)) break;
+    }
+    // (2) numbering: surviving nodes in their old order, then what their split cells spawn
+    uint32_t n_alive = 0, n_spawned = 0;
+    for (uint32_t k = 0; k * 64u < n; k++) {
+        const uint32_t i = k * 64u + lane;
+        const uint32_t d = i < n ? w.depth[i] : 0u;
+        uint32_t mine = 0;
+        if (d != 0u) {
+            const float4 v = t.rad[i];
+            const uint2 links = t.child[i];
+            const float r[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                uint32_t levels;
+                if (child_link(links, c) == 0u) mine += spawned_by_cell(r[c], total, a.threshold, d, levels, too_deep);
+            }
+        }
+        const unsigned long long alive = __ballot(d != 0u);
+        uint32_t x = mine;
+        for (uint32_t off = 1; off < 64u; off <<= 1) {
+            const uint32_t y = (uint32_t)__shfl_up((int)x, off);
+            if (lane >= off) x += y;
+        }
+        if (d != 0u) {
+            w.out_index[i] = (uint16_t)(n_alive + (uint32_t)__popcll(alive & ((1ull << lane) - 1ull)));
+            w.spawn_at[i] = (uint16_t)(n_spawned + x - mine);
+        }
+        n_alive += (uint32_t)__popcll(alive);
+        const uint32_t block_total = (uint32_t)__shfl((int)x, 63);
+        n_spawned = n_spawned + block_total < n_spawned ? 0xffffffffu : n_spawned + block_total;  // (saturating)
+    }
+    wave_sync_lds();
+    const uint32_t size = n_spawned > 0xffffu ? 0x10000u : n_alive + n_spawned;
+    if (!WRITE) {
+        if (too_deep) atomicAdd(a.guards + kGuardQuadLevel, too_deep);
+        if (size > 65535u && lane == 0u) *a.error_flag = 1u;
+        return size;
+    }
+    if (size > 65535u) return size;  // (the count pass has flagged it; the host fails the wave)
+    // (3) topology
+    for (uint32_t k = 0; k * 64u < n; k++) {
+        const uint32_t i = k * 64u + lane;
+        const uint32_t d = i < n ? w.depth[i] : 0u;
+        if (d == 0u) continue;
+        const float4 v = t.rad[i];
+        const uint2 links = t.child[i];
+        const float r[4] = {v.x, v.y, v.z, v.w};
+        uint32_t cursor = n_alive + w.spawn_at[i], out_link[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const uint32_t link = child_link(links, c);
+            if (link != 0u) {
+                if (link < n && w.depth[link] != 0u) out_link[c] = w.out_index[link];
+                continue;
+            }
+            uint32_t levels, unused = 0;
+            const uint32_t nodes = spawned_by_cell(r[c], total, a.threshold, d, levels, unused);
+            if (nodes == 0u) continue;
+            out_link[c] = cursor;
+            uint32_t level_at = cursor, width = 1;  // the subtree level by level; node q of a level has children 4q .. 4q + 3 of the next
+            for (uint32_t j = 0; j < levels; j++) {
+                const uint32_t next_at = level_at + width;
+                for (uint32_t q = 0; q < width; q++) {
+                    const uint32_t f = next_at + 4u * q;
+                    a.new_child[new_base + level_at + q] = j + 1u < levels ? make_uint2(f | ((f + 1u) << 16), (f + 2u) | ((f + 3u) << 16)) : make_uint2(0u, 0u);
+                }
+                level_at = next_at;
+                width *= 4u;
+            }
+            cursor += nodes;
+        }
+        a.new_child[new_base + w.out_index[i]] = make_uint2(out_link[0] | (out_link[1] << 16), out_link[2] | (out_link[3] << 16));
+    }
+    return size;
+}
+
 // Per NEW leaf: the sampling copy (emit_into), whether that copy's mean is zero, and the size of the reshaped collector.
 template <uint32_t LANES>
 __global__ __launch_bounds__(kBlock) void k_refine_emit_count(RefineArgs a) {
@@ -188,13 +360,17 @@ __global__ __launch_bounds__(kBlock) void k_refine_emit_count(RefineArgs a) {
         }
     }
     wave_sync_lds();
+    if (staged) {  // the whole wave (reshape_collector_wave)
+        const uint32_t size = reshape_collector_wave<false>(a, t, sm[LANES == 64u ? threadIdx.x / 64u : 0u].par, n, 0u);
+        if (lane == 0) a.new_size[leaf] = size;
+    }
     if (lane != 0) return;
     float weight = a.old_weight[src];
     for (uint32_t k = 0; k < a.halvings[leaf]; k++) weight /= 2.0f;  // STree split: collector weight halves (stree.rs:55-101)
     // DTree::mean() == 0 (dtree.rs:71-77) decides between uniform and tree sampling
     const float mean = weight == 0.0f ? 0.0f : sum4(a.old_rad[ob]) / (kFourPi * weight);
-    if (staged) a.new_size[leaf] = reshape_collector<false>(a, t.rad, t.child, 0u, lds_stack);  // (separate instances: see k_refine_sums)
-    else if (LANES == 64u) a.new_size[leaf] = reshape_collector<false>(a, a.old_rad + ob, a.old_child + ob, 0u, lds_stack);
+    if (staged) {
+    } else if (LANES == 64u) a.new_size[leaf] = reshape_collector<false>(a, a.old_rad + ob, a.old_child + ob, 0u, lds_stack);  // (separate instances: see k_refine_sums)
     else {
         ReshapeItem stack[kReshapeStack];
         a.new_size[leaf] = reshape_collector<false>(a, a.old_rad + ob, a.old_child + ob, 0u, stack);
@@ -219,10 +395,11 @@ __global__ __launch_bounds__(kBlock) void k_refine_write(RefineArgs a) {
         }
         wave_sync_lds();
     }
-    if (lane != 0) return;
     const uint32_t nb = a.new_off[leaf];
-    if (staged) (void)reshape_collector<true>(a, t.rad, t.child, nb, lds_stack);
-    else if (LANES == 64u) (void)reshape_collector<true>(a, a.old_rad + ob, a.old_child + ob, nb, lds_stack);
+    if (staged) (void)reshape_collector_wave<true>(a, t, sm[LANES == 64u ? threadIdx.x / 64u : 0u].par, n, nb);  // the whole wave
+    if (lane != 0) return;
+    if (staged) {
+    } else if (LANES == 64u) (void)reshape_collector<true>(a, a.old_rad + ob, a.old_child + ob, nb, lds_stack);
     else {
         ReshapeItem stack[kReshapeStack];
         (void)reshape_collector<true>(a, a.old_rad + ob, a.old_child + ob, nb, stack);
@@ -230,28 +407,55 @@ __global__ __launch_bounds__(kBlock) void k_refine_write(RefineArgs a) {
     a.leaf_info[leaf].y = nb;
 }
 
-// Exclusive scan of `n` counts by one workgroup (n is the number of spatial leaves: 1..10^6); out[n] = total.
-__global__ __launch_bounds__(1024) void k_exclusive_scan(const uint32_t* in, uint32_t* out, uint32_t n) {
-    __shared__ uint32_t sm[1024];
-    const uint32_t t = threadIdx.x, per = (n + 1023u) / 1024u;
-    const uint32_t lo = t * per < n ? t * per : n, hi = lo + per < n ? lo + per : n;
-    uint32_t s = 0;
-    for (uint32_t i = lo; i < hi; i++) s += in[i];
-    sm[t] = s;
-    __syncthreads();
-    for (uint32_t off = 1; off < 1024u; off <<= 1) {
-        const uint32_t v = t >= off ? sm[t - off] : 0u;
-        __syncthreads();
-        sm[t] += v;
-        __syncthreads();
+// Exclusive scan of `n` counts by one workgroup (n: spatial leaves or nodes, 1..10^6); out[n] = total. Tiles of 4096
+// consecutive elements, four per thread in one 16-byte load (in and out are buffer bases: 16-byte aligned), the next tile
+// requested before this one is scanned: a tile costs six shuffles, one barrier and the sixteen wave totals. (The first
+// version gave every thread n / 1024 consecutive elements — 64 different lines per load instruction: 57 us for 42 k elements.)
+PT_D void block_exclusive_scan(const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* total_out) {
+    __shared__ uint32_t sm_totals[2][16];
+    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+    const auto fetch = [&](uint32_t base) {
+        const uint32_t i = base + 4u * t;
+        if (i + 3u < n) return *reinterpret_cast<const uint4*>(in + i);
+        return make_uint4(i < n ? in[i] : 0u, i + 1u < n ? in[i + 1u] : 0u, i + 2u < n ? in[i + 2u] : 0u, 0u);
+    };
+    uint4 cur = fetch(0u);
+    uint32_t carry = 0, flip = 0;
+    for (uint32_t base = 0; base < n; base += 4096u, flip ^= 1u) {
+        uint4 nxt = make_uint4(0u, 0u, 0u, 0u);
+        if (base + 4096u < n) nxt = fetch(base + 4096u);
+        const uint32_t mine = cur.x + cur.y + cur.z + cur.w;
+        uint32_t x = mine;
+        for (uint32_t off = 1; off < 64u; off <<= 1) {
+            const uint32_t y = (uint32_t)__shfl_up((int)x, off);
+            if (lane >= off) x += y;
+        }
+        if (lane == 63u) sm_totals[flip][wave] = x;
+        __syncthreads();  // (one per tile: the other buffer is written next, and nobody passes THAT tile's barrier while a wave still reads this one)
+        uint32_t before = 0, all = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < 16u; w++) {
+            const uint32_t v = sm_totals[flip][w];
+            before += w < wave ? v : 0u;
+            all += v;
+        }
+        const uint32_t first = carry + before + x - mine, i = base + 4u * t;
+        const uint4 o = make_uint4(first, first + cur.x, first + cur.x + cur.y, first + cur.x + cur.y + cur.z);
+        if (i + 3u < n) *reinterpret_cast<uint4*>(out + i) = o;
+        else {
+            if (i < n) out[i] = o.x;
+            if (i + 1u < n) out[i + 1u] = o.y;
+            if (i + 2u < n) out[i + 2u] = o.z;
+        }
+        carry += all;
+        cur = nxt;
     }
-    uint32_t run = sm[t] - s;
-    for (uint32_t i = lo; i < hi; i++) {
-        out[i] = run;
-        run += in[i];
+    if (t == 0) {
+        out[n] = carry;
+        if (total_out) *total_out = carry;
     }
-    if (t == 1023u) out[n] = sm[1023];
 }
+__global__ __launch_bounds__(1024) void k_exclusive_scan(const uint32_t* in, uint32_t* out, uint32_t n) { block_exclusive_scan(in, out, n, nullptr); }
 
 // ---------------------------------------------------------------------------------------------------------------
 // The spatial half of STree::new_iteration on the device: STree::subdivide_nodes (stree.rs:55-101), the numbering of
@@ -335,32 +539,10 @@ __global__ __launch_bounds__(kBlock) void k_stree_plan(StreeArgs a) {
 }
 
 // The scans of the spatial refinement: as k_exclusive_scan, with the element count read from the header (the host does
-// not know it yet). n = min(header[word] * per, cap); the total also goes to *total_out when given.
+// not know it yet). n = min(header[word] * per_unit, cap); the total also goes to *total_out when given.
 __global__ __launch_bounds__(1024) void k_exclusive_scan_dev(const uint32_t* in, uint32_t* out, const uint32_t* header, uint32_t word, uint32_t per_unit, uint32_t cap, uint32_t* total_out) {
-    __shared__ uint32_t sm[1024];
     const unsigned long long want = (unsigned long long)header[word] * per_unit;
-    const uint32_t n = want < cap ? (uint32_t)want : cap;
-    const uint32_t t = threadIdx.x, per = (n + 1023u) / 1024u;
-    const uint32_t lo = t * per < n ? t * per : n, hi = lo + per < n ? lo + per : n;
-    uint32_t s = 0;
-    for (uint32_t i = lo; i < hi; i++) s += in[i];
-    sm[t] = s;
-    __syncthreads();
-    for (uint32_t off = 1; off < 1024u; off <<= 1) {
-        const uint32_t v = t >= off ? sm[t - off] : 0u;
-        __syncthreads();
-        sm[t] += v;
-        __syncthreads();
-    }
-    uint32_t run = sm[t] - s;
-    for (uint32_t i = lo; i < hi; i++) {
-        out[i] = run;
-        run += in[i];
-    }
-    if (t == 1023u) {
-        out[n] = sm[1023];
-        if (total_out) *total_out = sm[1023];
-    }
+    block_exclusive_scan(in, out, want < cap ? (uint32_t)want : cap, total_out);
 }
 
 PT_D bool stree_fits(const StreeArgs& a) {
