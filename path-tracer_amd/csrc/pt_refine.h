@@ -554,7 +554,7 @@ PT_D bool stree_fits(const StreeArgs& a) {
 // One thread per (level, old node): level 0 is the old node itself, level L >= 1 its block of 2^L appended nodes.
 __global__ __launch_bounds__(kBlock) void k_stree_append(StreeArgs a) {
     const uint32_t levels = a.header[kHdrLevels];
-    if (blockIdx.x == 0 && threadIdx.x == 0) {  // the capacity verdict, once
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {  // the capacity verdict, once
         const unsigned long long arena = ((unsigned long long)a.header[kHdrArenaHi] << 32) | a.header[kHdrArenaLo];
         uint32_t f = 0;
         if (a.header[kHdrNodes] > a.cap_nodes) f |= kStreeNodesOver;
@@ -571,6 +571,7 @@ __global__ __launch_bounds__(kBlock) void k_stree_append(StreeArgs a) {
     const uint32_t h = a.halvings_of[i];
     const auto start_of = [&](uint32_t l) { return a.n_old_nodes + a.block_start[(size_t)(l - 1u) * a.n_old_nodes + i]; };  // first node of leaf i's level-l block
     if (level == 0u) {
+        if (blockIdx.y != 0u) return;
         if (n.x != 0u) {
             a.new_nodes[i] = make_uint4(n.x, n.y, n.z, 0xffffffffu);
             a.is_leaf[i] = 0u;
@@ -591,7 +592,7 @@ __global__ __launch_bounds__(kBlock) void k_stree_append(StreeArgs a) {
     if (n.x != 0u || h < level) return;
     const uint32_t base = start_of(level), axis = (n.z + level) % 3u, size = a.old_size[n.w];
     const uint32_t below = h > level ? start_of(level + 1u) : 0u;
-    for (uint32_t t = 0; t < (1u << level); t++) {
+    for (uint32_t t = blockIdx.y; t < (1u << level); t += gridDim.y) {  // (gridDim.y > 1 while the tree is young: one leaf becomes a thousand)
         const uint32_t idx = base + t;
         if (h > level) {
             a.new_nodes[idx] = make_uint4(below + 2u * t, below + 2u * t + 1u, axis, 0xffffffffu);
