@@ -8,7 +8,7 @@ HIPFLAGS = -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -munsafe-fp-at
 CSRC = $(PKG)/csrc
 GPU_DEPS = $(wildcard $(CSRC)/*.h $(CSRC)/*.inc) include/ptgpu.h
 
-all: $(LIB)/libptgpu.so $(LIB)/libpthost.so $(LIB)/pt $(LIB)/calib_fetch $(LIB)/rgb2spec_opt oracle
+all: $(LIB)/libptgpu.so $(LIB)/libpthost.so $(LIB)/pt $(LIB)/calib_fetch $(LIB)/calib_atomics $(LIB)/rgb2spec_opt oracle
 
 $(LIB)/libptgpu.so: $(CSRC)/ptgpu.hip $(CSRC)/bvh_build.cpp $(CSRC)/sdtree_host.cpp $(GPU_DEPS)
 	mkdir -p $(LIB)
@@ -30,6 +30,9 @@ rgb2spec-table: $(LIB)/rgb2spec_opt
 	$(LIB)/rgb2spec_opt --full $(LIB)/srgb.coeffs --slab $(PKG)/data/srgb_z05.coeffs
 
 # FETCH_SIZE calibration micro-benchmark (tools/gpu_calib_fetch.sh); a measuring tool, not part of the product
+$(LIB)/calib_atomics: tools/calib_atomics.hip
+	mkdir -p $(LIB)
+	$(HIPCC) -O3 -std=c++17 --offload-arch=gfx950 -o $@ tools/calib_atomics.hip
 $(LIB)/calib_fetch: tools/calib_fetch.hip
 	mkdir -p $(LIB)
 	$(HIPCC) -O3 -std=c++17 --offload-arch=gfx950 -o $@ tools/calib_fetch.hip
