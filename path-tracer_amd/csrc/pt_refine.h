@@ -56,7 +56,10 @@ PT_D uint32_t refine_new_leaves(const RefineArgs& a) { return !a.header ? a.n_ne
 // ~120 dependent round trips to memory however few the leaves); lazy push 37-75 against 36-257; sampling copy + count
 // 142 / 165 / 208 / 253 against 253 / 249 / 272 / 271; reshape + write 140 / 170 / 222 / 273 against 158 / 158 / 162 / 182.
 constexpr uint32_t kSumsWavePerLeafUpTo = 49152, kEmitWavePerLeafUpTo = 1u << 22, kWriteWavePerLeafUpTo = 1u << 22;  // (the reshape is wave-parallel since round 3: reshape_collector_wave)
-constexpr uint32_t kLeafTreeLds = 256;
+#ifndef PT_LEAF_TREE_LDS
+#define PT_LEAF_TREE_LDS 256  // (a multiple of 64; tests build a variant with 64 so that the serial fallback runs on real trees)
+#endif
+constexpr uint32_t kLeafTreeLds = PT_LEAF_TREE_LDS;
 constexpr uint32_t kLeavesPerBlock = kBlock / 64u;
 struct ReshapeItem {  // walk stack of reshape_collector
     uint32_t src_out;  // source node (0xffff = a cell split in this pass) | output index << 16
