@@ -1188,12 +1188,11 @@ struct RecordQueue {
     uint4* who;       // parity hook only (ptgpu_guided_capture_records), else NULL: {path id, vertex row, pixel, -} per record
 };
 
-__global__ __launch_bounds__(kBlock, PT_SCAN_WAVES) void k_guide_scan(SceneDev sc, RenderParams rp, GuidedParams gp, RecordQueue rq, uint32_t n_paths) {
+__global__ __launch_bounds__(kBlock, PT_SCAN_WAVES) void k_guide_scan(SceneDev sc, RenderParams rp, GuidedParams gp, RecordQueue rq, uint32_t n_paths, uint32_t first_chunk, uint32_t end_chunk) {
     __shared__ uint32_t sm_n;
     __shared__ float4 sm_stage[(kBlock / 64u) * 8u * 64u];  // per wave: the 64 lines of one row, on their way from the lanes that fetched them to their paths
-    const uint32_t n_chunks = (n_paths + kBlock - 1) / kBlock;
     const uint32_t lane = __lane_id();
-    for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+    for (uint32_t chunk = first_chunk + blockIdx.x; chunk < end_chunk; chunk += gridDim.x) {  // (chunks [first, end): the whole batch, or one slice of it)
         if (threadIdx.x == 0) sm_n = 0;
         __syncthreads();
         const uint32_t pid = chunk * kBlock + threadIdx.x;
@@ -1442,10 +1441,9 @@ constexpr uint32_t kBinStackLds = 4;   // walk-stack entries in LDS (owed subtre
 constexpr uint32_t kBinSpillDepth = 3 * kMaxQuadLevel + 4 - kBinStackLds;  // walk-stack entries beyond the LDS part
 constexpr uint32_t kBinTreeCap = 192;  // quadtree nodes held in LDS (the 1 % subdivision threshold keeps trees near 10^2 nodes); larger trees take the direct path
 
-__global__ __launch_bounds__(kBlock) void k_guide_locate(SdTreeDev tree, GuidedParams gp, RecordQueue rq, RecordBins bins, uint32_t n_paths) {
-    const uint32_t n_chunks = (n_paths + kBlock - 1) / kBlock;
+__global__ __launch_bounds__(kBlock) void k_guide_locate(SdTreeDev tree, GuidedParams gp, RecordQueue rq, RecordBins bins, uint32_t first_chunk, uint32_t end_chunk) {
     const uint32_t lane = __lane_id();
-    for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+    for (uint32_t chunk = first_chunk + blockIdx.x; chunk < end_chunk; chunk += gridDim.x) {
         const uint32_t n = rq.count[chunk];
         const size_t base = (size_t)chunk * kBlock * gp.n_rows;
         for (uint32_t j0 = 0; j0 < n; j0 += kBlock) {

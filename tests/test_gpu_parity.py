@@ -452,9 +452,11 @@ def test_binned_record_pass_equals_direct_splat(gpu_ctx):
     sc = pt.LoadedScene("cornell-box-guided", resx=96, resy=96, max_depth=8)
     gpu_ctx.load(sc)
     stats = {}
-    for mode in ("binned", "direct"):
-        if mode == "direct":
-            os.environ["PTGPU_DIRECT_SPLAT"] = "1"
+    # "sliced": what large batches do — the queue goes through k_guide_scan and k_guide_locate in four slices, the locate
+    # of one slice on a third stream beside the scan of the next (here forced onto a batch of 36 chunks)
+    env_of = {"binned": {}, "sliced": {"PTGPU_RECORD_SLICES_FROM": "1", "PTGPU_RECORD_SLICES": "4"}, "direct": {"PTGPU_DIRECT_SPLAT": "1"}}
+    for mode in ("binned", "sliced", "direct"):
+        os.environ.update(env_of[mode])
         try:
             n_waves = gpu_ctx.guided_begin(sc.integrator, 7)
             per_wave = []
@@ -463,16 +465,19 @@ def test_binned_record_pass_equals_direct_splat(gpu_ctx):
                 per_wave.append(gpu_ctx.guided_stats_host())
             gpu_ctx.guided_end()
         finally:
-            os.environ.pop("PTGPU_DIRECT_SPLAT", None)
+            for k in env_of[mode]:
+                os.environ.pop(k, None)
         stats[mode] = per_wave
     # wave 0 trains the single-node tree, wave 1 the first refined one (dozens of nodes per quadtree, subtrees owed)
-    for w in (0, 1):
-        a, b = stats["binned"][w], stats["direct"][w]
-        assert a.shape == b.shape and a.size > 4
-        assert np.abs(a).sum() > 0
-        assert abs(a.sum() / b.sum() - 1.0) < 1e-4
-        scale = np.abs(b).max()
-        assert np.abs(a - b).max() < 2e-3 * scale, (w, np.abs(a - b).max(), scale)
+    for mode in ("binned", "sliced"):
+        for w in (0, 1):
+            a, b = stats[mode][w], stats["direct"][w]
+            assert a.shape == b.shape and a.size > 4
+            assert np.abs(a).sum() > 0
+            assert abs(a.sum() / b.sum() - 1.0) < 1e-4
+            scale = np.abs(b).max()
+            assert np.abs(a - b).max() < 2e-3 * scale, (mode, w, np.abs(a - b).max(), scale)
+    assert (stats["sliced"][0][-1:] == stats["binned"][0][-1:]).all()    # wave 0: one leaf, its weight = the record count, exactly
     assert stats["binned"][1].size > 100
 
 
