@@ -1497,9 +1497,8 @@ __global__ __launch_bounds__(kBlock) void k_guide_locate(SdTreeDev tree, GuidedP
     }
 }
 
-__global__ __launch_bounds__(kBlock) void k_guide_scatter(GuidedParams gp, RecordQueue rq, RecordBins bins, uint32_t n_paths) {
-    const uint32_t n_chunks = (n_paths + kBlock - 1) / kBlock;
-    for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+__global__ __launch_bounds__(kBlock) void k_guide_scatter(GuidedParams gp, RecordQueue rq, RecordBins bins, uint32_t first_chunk, uint32_t end_chunk) {
+    for (uint32_t chunk = first_chunk + blockIdx.x; chunk < end_chunk; chunk += gridDim.x) {
         const uint32_t n = rq.count[chunk];
         const size_t base = (size_t)chunk * kBlock * gp.n_rows;
         for (uint32_t j = threadIdx.x; j < n; j += kBlock) {

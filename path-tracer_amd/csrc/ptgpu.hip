@@ -120,8 +120,11 @@ struct ptgpu_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;  // guided: the record pass of batch b runs here while `stream` walks batch b + 1
-    hipStream_t stream3 = nullptr;  // guided: k_guide_locate of one slice of a batch's records runs here beside k_guide_scan of the next (stream2)
-    hipEvent_t ev_slice[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // scan of slice i done; [8]: every slice located
+    // guided: a large batch's records go through the record pass in slices, pipelined over three streams: k_guide_scan of a slice
+    // on stream2, its locate / count scan / scatter on stream3, its splat on stream4
+    hipStream_t stream3 = nullptr, stream4 = nullptr;
+    static constexpr int kMaxRecordSlices = 16;
+    hipEvent_t ev_scanned[kMaxRecordSlices] = {}, ev_grouped[kMaxRecordSlices] = {}, ev_splatted = nullptr;
     int n_cus = 256;
     // scene
     bool have_scene = false, have_camera = false;
@@ -381,8 +384,12 @@ int ptgpu_init(ptgpu_ctx** out, int device_id) {
     hipError_t e = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_greatest);
     if (e == hipSuccess) e = hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_least);
     if (e == hipSuccess) e = hipStreamCreateWithPriority(&c->stream3, hipStreamNonBlocking, prio_least);
-    for (hipEvent_t& ev : c->ev_slice)
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipStreamCreateWithPriority(&c->stream4, hipStreamNonBlocking, prio_least);
+    for (int k = 0; k < ptgpu_ctx::kMaxRecordSlices; k++) {
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_scanned[k], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_grouped[k], hipEventDisableTiming);
+    }
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_splatted, hipEventDisableTiming);
     if (e == hipSuccess) e = hipGetSymbolAddress((void**)&c->scratch, HIP_SYMBOL(scratch));  // this device's copy of the array
     if (e == hipSuccess) e = c->d_census.alloc(4);
     if (e == hipSuccess) e = hipMemset(c->d_census.p, 0, 4 * sizeof(unsigned long long));
@@ -404,14 +411,19 @@ void ptgpu_destroy(ptgpu_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     if (c->stream2) (void)hipStreamSynchronize(c->stream2);
     if (c->stream3) (void)hipStreamSynchronize(c->stream3);
+    if (c->stream4) (void)hipStreamSynchronize(c->stream4);
     guided_free(c->guided);
     guided_persist_free(c->guided_persist);
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->stream3) (void)hipStreamDestroy(c->stream3);
-    for (hipEvent_t ev : c->ev_slice)
-        if (ev) (void)hipEventDestroy(ev);
+    if (c->stream4) (void)hipStreamDestroy(c->stream4);
+    for (int k = 0; k < ptgpu_ctx::kMaxRecordSlices; k++) {
+        if (c->ev_scanned[k]) (void)hipEventDestroy(c->ev_scanned[k]);
+        if (c->ev_grouped[k]) (void)hipEventDestroy(c->ev_grouped[k]);
+    }
+    if (c->ev_splatted) (void)hipEventDestroy(c->ev_splatted);
     delete c;
 }
 
