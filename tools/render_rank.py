@@ -13,7 +13,7 @@ world = int(args[0]) if len(args) > 0 else 8
 ctx = pt.Context(0)
 sc = pt.LoadedScene("cornell-box-guided"); ctx.load(sc)
 if len(args) > 2: ctx.set_batch_paths(int(args[2]))
-ctx.render(sc.integrator, 64)
+ctx.render(sc.integrator, 512)  # (buffers grow to the job's size here, not in the timed render)
 t = time.time(); ctx.render(sc.integrator, 512); one = time.time() - t
 print(f"N=1: 512 spp in {1e3 * one:.1f} ms", flush=True)
 for rep in range(int(args[1]) if len(args) > 1 else 2):
