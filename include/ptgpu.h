@@ -82,8 +82,11 @@ typedef struct ptgpu_integrator_desc {
     int32_t mode;                /* PTGPU_MODE_* (path, guided) */
     float spatial_threshold;     /* guided: `spatial_threashold` */
     float directional_threshold; /* guided: carried for fidelity; render uses 0.01 like path_guiding/mod.rs:73 */
-    int32_t spatial_filter;      /* guided: must be STOCHASTIC, the only value the reference's parser selects (parser/mod.rs:144) */
-    int32_t directional_filter;  /* guided: must be BOX (parser/mod.rs:145); anything else fails with PTGPU_E_INVALID.
+    int32_t spatial_filter;      /* guided: STOCHASTIC, the only value the reference's parser selects (parser/mod.rs:144;
+                                  * stree.rs:186-201), or NEAREST (stree.rs:117-126). BOX (stree.rs:127-185: one record
+                                  * into every leaf its footprint overlaps) fails with PTGPU_E_INVALID */
+    int32_t directional_filter;  /* guided: BOX (parser/mod.rs:145; dtree.rs:235-289) or NEAREST (dtree.rs:208-222).
+                                  * STOCHASTIC (dtree.rs:223-234) fails with PTGPU_E_INVALID.
                                   * Deviation: a directional quadtree is at most 24 levels deep here (cells of 2^-24; the
                                   * reference has no cap, its u16 node links bound the node count only) */
 } ptgpu_integrator_desc;

@@ -389,6 +389,14 @@ orc_sdtree* orc_sdtree_create(const float* bounds6, const uint32_t* spatial, uin
     return t;
 }
 void orc_sdtree_destroy(orc_sdtree* t) { delete t; }
+// The filters of STree::new (stree.rs:21-34) on an existing tree: the spatial one, and the directional one of every DTree.
+void orc_sdtree_set_filters(orc_sdtree* t, int32_t spatial, int32_t directional) {
+    t->guider.stree.filter = (Filter)spatial;
+    for (STreeNode& n : t->guider.stree.nodes) {
+        n.sampler.filter = (Filter)directional;
+        n.collector.filter = (Filter)directional;
+    }
+}
 
 // out[5] = spatial nodes, leaves, reachable sampling nodes, reachable collector nodes, deepest quadtree level (root = 1)
 void orc_sdtree_sizes(orc_sdtree* t, uint32_t* out) {

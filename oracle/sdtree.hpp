@@ -360,18 +360,20 @@ struct STree {
         B3 footprint = B3::around(p3, lb.extent()).clamp(bounds.min, bounds.max);
         record_box_recursive(bounds, footprint, p2, radiance, 0, sampler);
     }
+    void log_record(V3 p3, V3 wi, float radiance, float u0, float u1, float u2, size_t ni) {  // test hook (RecordLog)
+        if (!log) return;
+        const RecordKey k = record_key();
+        const float f[10] = {p3.x, p3.y, p3.z, wi.x, wi.y, wi.z, radiance, u0, u1, u2};
+        uint32_t w[14];
+        std::memcpy(w, f, sizeof(f));
+        w[10] = (uint32_t)ni; w[11] = k.pixel; w[12] = k.pass; w[13] = k.vertex;
+        std::lock_guard<std::mutex> g(log->m);
+        log->words.insert(log->words.end(), w, w + 14);
+    }
     void record_stochastic(V3 p3, V3 wi, V2 p2, float radiance, Sampler& sampler) {  // stree.rs:186-201
         float u0 = sampler.sample1d(), u1 = sampler.sample1d(), u2 = sampler.sample1d();
         size_t ni = record_stochastic_drawn(p3, p2, radiance, u0, u1, u2, sampler);
-        if (log) {
-            const RecordKey k = record_key();
-            const float f[10] = {p3.x, p3.y, p3.z, wi.x, wi.y, wi.z, radiance, u0, u1, u2};
-            uint32_t w[14];
-            std::memcpy(w, f, sizeof(f));
-            w[10] = (uint32_t)ni; w[11] = k.pixel; w[12] = k.pass; w[13] = k.vertex;
-            std::lock_guard<std::mutex> g(log->m);
-            log->words.insert(log->words.end(), w, w + 14);
-        }
+        log_record(p3, wi, radiance, u0, u1, u2, ni);
     }
     // the body of record_stochastic after its three draws (split off so that a test can replay given draws); -> leaf node
     size_t record_stochastic_drawn(V3 p3, V2 p2, float radiance, float u0, float u1, float u2, Sampler& sampler) {
@@ -392,7 +394,7 @@ struct STree {
         if (radiance == 0.0f) return;
         V2 p2 = dir_to_square(wi);
         switch (filter) {
-            case Filter::Nearest: record_nearest(p, p2, radiance, sampler); break;
+            case Filter::Nearest: log_record(p, wi, radiance, 0.0f, 0.0f, 0.0f, record_nearest(p, p2, radiance, sampler)); break;
             case Filter::Box: record_box(p, p2, radiance, sampler); break;
             case Filter::Stochastic: record_stochastic(p, wi, p2, radiance, sampler); break;
         }

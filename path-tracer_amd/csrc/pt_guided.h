@@ -705,6 +705,8 @@ struct GuidedParams {
     uint32_t record;       // 0: the scan only folds the paths into the film (ptgpu_set_final_training(0), last wave)
     uint32_t shard_index, shard_count;
     uint32_t tiles_x, n_tiles;
+    uint32_t spatial_nearest;      // STree filter Nearest instead of Stochastic (stree.rs:117-126): no jitter, no draws
+    uint32_t directional_nearest;  // DTree filter Nearest instead of Box (dtree.rs:208-222)
 };
 
 PT_HD uint32_t tile_of_pixel(uint32_t pixel, uint32_t resx, uint32_t tiles_x) { return (pixel / resx / 16u) * tiles_x + (pixel % resx) / 16u; }
@@ -1243,7 +1245,7 @@ __global__ __launch_bounds__(kBlock, PT_SCAN_WAVES) void k_guide_scan(SceneDev s
             if (v < nverts) {
                 radiance = spec_average(l) / pp.w;
                 want = isfinite(radiance) && radiance != 0.0f;  // STree::record's early return (stree.rs:102-116)
-                if (want) {
+                if (want && !gp.spatial_nearest) {  // the stochastic filter's three draws (stree.rs:195-199); the nearest filter draws nothing
                     u0 = rng_f32(rng);
                     u1 = rng_f32(rng);
                     u2 = rng_f32(rng);
@@ -1459,12 +1461,15 @@ __global__ __launch_bounds__(kBlock) void k_guide_locate(SdTreeDev tree, GuidedP
                 radiance = a.w;
                 sq = dir_to_square(mk3(b.x, b.y, b.z));
                 V3 lo, hi;
-                (void)stree_leaf<true>(tree, p, lo, hi);
-                const V3 ext = hi - lo;
-                const V3 jlo = p - ext / 2.0f;  // Bounds3::around(p, extent)
-                const V3 jhi = p + ext / 2.0f;
-                const V3 q = clamp3(jlo + mk3(b.w, c.x, c.y) * (jhi - jlo), tree.blo, tree.bhi);
-                leaf_id = stree_leaf<false>(tree, q, lo, hi);
+                if (gp.spatial_nearest) leaf_id = stree_leaf<false>(tree, p, lo, hi);  // STree::record_nearest (stree.rs:117-126)
+                else {
+                    (void)stree_leaf<true>(tree, p, lo, hi);
+                    const V3 ext = hi - lo;
+                    const V3 jlo = p - ext / 2.0f;  // Bounds3::around(p, extent)
+                    const V3 jhi = p + ext / 2.0f;
+                    const V3 q = clamp3(jlo + mk3(b.w, c.x, c.y) * (jhi - jlo), tree.blo, tree.bhi);
+                    leaf_id = stree_leaf<false>(tree, q, lo, hi);
+                }
             }
             // Position in the leaf's group. Young trees have few leaves (wave 0: one), and same-address atomics
             // serialise at the memory side: lanes that share the first active lane's leaf take ONE atomic together,
@@ -1580,7 +1585,26 @@ PT_D void dtree_record_box_lane(const uint2* links_of, float* sums_of, float* la
     }
 }
 
-__global__ __launch_bounds__(kBinBlock) void k_guide_splat_bins(SdTreeDev tree, RecordBins bins, uint32_t per_block, uint2* spill_base) {
+// DTree::record with the nearest filter (dtree.rs:208-222): the whole radiance to the leaf cell that holds p.
+template <bool LDS_TREE>
+PT_D void dtree_record_nearest_lane(const uint2* links_of, float* sums_of, V2 p, float radiance) {
+    Cell cell{0, 0, 0};
+    uint32_t ni = 0;
+    for (;;) {
+        Cell child;
+        const int c = cell_child_of(cell, p, child);
+        const uint32_t link = child_link(links_of[ni], c);
+        if (link == 0 || child.level >= kMaxQuadLevel) {
+            if (LDS_TREE) atomicAdd(sums_of + 4 * ni + c, radiance);
+            else unsafeAtomicAdd(sums_of + 4 * ni + c, radiance);
+            return;
+        }
+        cell = child;
+        ni = link;
+    }
+}
+
+__global__ __launch_bounds__(kBinBlock) void k_guide_splat_bins(SdTreeDev tree, RecordBins bins, uint32_t per_block, uint2* spill_base, uint32_t nearest) {
     __shared__ uint2 sm_links[kBinTreeCap];
     __shared__ float sm_sums[4 * kBinTreeCap];
     __shared__ float sm_lazy[4 * kBinTreeCap];
@@ -1603,7 +1627,8 @@ __global__ __launch_bounds__(kBinBlock) void k_guide_splat_bins(SdTreeDev tree, 
                 __syncthreads();
                 for (uint32_t j = pos + threadIdx.x; j < run_end; j += kBinBlock) {
                     const float4 r = bins.grouped[j];
-                    dtree_record_box_lane<true>(sm_links, sm_sums, sm_lazy, V2{r.x, r.y}, r.z, sm_stack + threadIdx.x, spill, spill_stride);
+                    if (nearest) dtree_record_nearest_lane<true>(sm_links, sm_sums, V2{r.x, r.y}, r.z);
+                    else dtree_record_box_lane<true>(sm_links, sm_sums, sm_lazy, V2{r.x, r.y}, r.z, sm_stack + threadIdx.x, spill, spill_stride);
                 }
                 __syncthreads();
                 for (uint32_t k = threadIdx.x; k < 4 * n_nodes; k += kBinBlock) {
@@ -1615,7 +1640,8 @@ __global__ __launch_bounds__(kBinBlock) void k_guide_splat_bins(SdTreeDev tree, 
             } else {
                 for (uint32_t j = pos + threadIdx.x; j < run_end; j += kBinBlock) {
                     const float4 r = bins.grouped[j];
-                    dtree_record_box_lane<false>(tree.c_child + c_off, sums_hbm, lazy_hbm, V2{r.x, r.y}, r.z, sm_stack + threadIdx.x, spill, spill_stride);
+                    if (nearest) dtree_record_nearest_lane<false>(tree.c_child + c_off, sums_hbm, V2{r.x, r.y}, r.z);
+                    else dtree_record_box_lane<false>(tree.c_child + c_off, sums_hbm, lazy_hbm, V2{r.x, r.y}, r.z, sm_stack + threadIdx.x, spill, spill_stride);
                 }
             }
             if (threadIdx.x == 0) unsafeAtomicAdd(tree.c_weight + leaf_id, (float)(run_end - pos));  // DTree::record: weight += 1 per record

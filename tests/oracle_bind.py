@@ -40,6 +40,7 @@ def load():
         lib.orc_sdtree_create.restype = C.c_void_p
         lib.orc_sdtree_create.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32] + [C.c_void_p] * 6 + [C.c_float]
         lib.orc_sdtree_destroy.argtypes = [C.c_void_p]
+        lib.orc_sdtree_set_filters.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
         lib.orc_sdtree_sizes.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
         lib.orc_sdtree_export.argtypes = [C.c_void_p] * 10
         lib.orc_sdtree_probe.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_uint32, C.c_uint64, C.c_void_p]
@@ -140,17 +141,23 @@ class OracleSdTree:
         self.handle = handle
 
     @classmethod
-    def fresh(cls, oscene: "OracleScene", spatial_threshold: float):
-        return cls(load().orc_sdtree_fresh(oscene.handle, spatial_threshold))
+    def fresh(cls, oscene: "OracleScene", spatial_threshold: float, filters=None):
+        return cls(load().orc_sdtree_fresh(oscene.handle, spatial_threshold)).with_filters(filters)
+
+    def with_filters(self, filters):
+        """filters = (spatial, directional) as in ptgpu_integrator_desc, or None for the reference parser's (stochastic, box)."""
+        if filters is not None:
+            self.lib.orc_sdtree_set_filters(self.handle, int(filters[0]), int(filters[1]))
+        return self
 
     @classmethod
-    def from_arrays(cls, t: dict, spatial_threshold: float):
+    def from_arrays(cls, t: dict, spatial_threshold: float, filters=None):
         a = {k: np.ascontiguousarray(t[k]) for k in TREE_KEYS}
         b = np.ascontiguousarray(t["bounds"], dtype=np.float32)
         assert a["spatial"].dtype == np.uint32 and a["leaf"].dtype == np.uint32 and a["s_child"].dtype == np.uint16 and a["c_child"].dtype == np.uint16
         vp = lambda x: x.ctypes.data_as(C.c_void_p)  # noqa: E731
         return cls(load().orc_sdtree_create(vp(b), vp(a["spatial"]), len(a["spatial"]), vp(a["leaf"]), len(a["leaf"]), vp(a["s_rad"]), vp(a["s_child"]),
-                                            vp(a["s_weight"]), vp(a["c_rad"]), vp(a["c_child"]), vp(a["c_weight"]), spatial_threshold))
+                                            vp(a["s_weight"]), vp(a["c_rad"]), vp(a["c_child"]), vp(a["c_weight"]), spatial_threshold)).with_filters(filters)
 
     def close(self):
         if self.handle:

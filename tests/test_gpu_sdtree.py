@@ -262,22 +262,30 @@ def compare_record_queues(g, c, extent, wave):
     return out
 
 
-@pytest.mark.parametrize("name,res,spp,depth,thr", [
-    ("cornell-box-guided", (64, 64), 63, 8, 200.0),
-    ("veach-bidir", (64, 64), 31, 32, 200.0),     # BASELINE configs[4] at reduced size: deep specular chains, smooth normals
-    ("veach-mis", (80, 48), 31, 32, 200.0),       # configs[4], the scene with the most triangles: GGX conductors, 61 440 emitters
+PARSER_FILTERS = (pt.FILTER_STOCHASTIC, pt.FILTER_BOX)   # what the reference's parser selects (parser/mod.rs:144-145)
+
+
+@pytest.mark.parametrize("name,res,spp,depth,thr,filters", [
+    ("cornell-box-guided", (64, 64), 63, 8, 200.0, PARSER_FILTERS),
+    ("veach-bidir", (64, 64), 31, 32, 200.0, PARSER_FILTERS),     # BASELINE configs[4] at reduced size: deep specular chains, smooth normals
+    ("veach-mis", (80, 48), 31, 32, 200.0, PARSER_FILTERS),       # configs[4], the scene with the most triangles: GGX conductors, 61 440 emitters
+    # the filters the parser cannot select but STree::record / DTree::record implement (stree.rs:117-126, dtree.rs:208-222)
+    ("cornell-box-guided", (64, 64), 63, 8, 200.0, (pt.FILTER_NEAREST, pt.FILTER_BOX)),
+    ("cornell-box-guided", (64, 64), 63, 8, 200.0, (pt.FILTER_STOCHASTIC, pt.FILTER_NEAREST)),
+    ("cornell-box-guided", (64, 64), 63, 8, 200.0, (pt.FILTER_NEAREST, pt.FILTER_NEAREST)),
 ])
-def test_guided_render_in_lock_step_with_oracle(gpu_ctx, name, res, spp, depth, thr):
+def test_guided_render_in_lock_step_with_oracle(gpu_ctx, name, res, spp, depth, thr, filters):
     """(iv): wave by wave from the same sampling tree; the image of the last wave pixel by pixel."""
     sc = pt.LoadedScene(name, resx=res[0], resy=res[1], max_depth=depth, integrator="guided")
     o = ob.OracleScene(sc)
     gpu_ctx.load(sc)
     integ = pt.IntegratorDesc.from_buffer_copy(sc.integrator)
     integ.spatial_threshold = thr
+    integ.spatial_filter, integ.directional_filter = filters
     waves = waves_of(spp)
     guards_before = gpu_ctx.guard_counts()
     assert gpu_ctx.guided_begin(integ, spp) == len(waves)
-    O = ob.OracleSdTree.fresh(o, thr)
+    O = ob.OracleSdTree.fresh(o, thr, filters)
     first = 0
     film_o = None
     rays = [0, 0, 0, 0]
@@ -324,7 +332,7 @@ def test_guided_render_in_lock_step_with_oracle(gpu_ctx, name, res, spp, depth, 
                   f"median {np.median(rel_leaf):.2e}, worst {rel_leaf.max():.2e}")
         # both refine from the GPU's statistics
         O.close()
-        O = ob.OracleSdTree.from_arrays(t, thr)
+        O = ob.OracleSdTree.from_arrays(t, thr, filters)
         if w + 1 < len(waves):
             gpu_ctx.guided_refine()
             O.new_iteration(w)
