@@ -85,8 +85,8 @@ typedef struct ptgpu_integrator_desc {
     int32_t spatial_filter;      /* guided: STOCHASTIC, the only value the reference's parser selects (parser/mod.rs:144;
                                   * stree.rs:186-201), or NEAREST (stree.rs:117-126). BOX (stree.rs:127-185: one record
                                   * into every leaf its footprint overlaps) fails with PTGPU_E_INVALID */
-    int32_t directional_filter;  /* guided: BOX (parser/mod.rs:145; dtree.rs:235-289) or NEAREST (dtree.rs:208-222).
-                                  * STOCHASTIC (dtree.rs:223-234) fails with PTGPU_E_INVALID.
+    int32_t directional_filter;  /* guided: BOX (parser/mod.rs:145; dtree.rs:235-289), NEAREST (dtree.rs:208-222) or
+                                  * STOCHASTIC (dtree.rs:223-234: two more draws per record).
                                   * Deviation: a directional quadtree is at most 24 levels deep here (cells of 2^-24; the
                                   * reference has no cap, its u16 node links bound the node count only) */
 } ptgpu_integrator_desc;

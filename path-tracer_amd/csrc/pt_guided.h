@@ -706,7 +706,7 @@ struct GuidedParams {
     uint32_t shard_index, shard_count;
     uint32_t tiles_x, n_tiles;
     uint32_t spatial_nearest;      // STree filter Nearest instead of Stochastic (stree.rs:117-126): no jitter, no draws
-    uint32_t directional_nearest;  // DTree filter Nearest instead of Box (dtree.rs:208-222)
+    uint32_t directional_filter;   // DTree filter: 1 = Box (dtree.rs:235-289), 0 = Nearest (dtree.rs:208-222), 2 = Stochastic (dtree.rs:223-234: two more draws per record)
 };
 
 PT_HD uint32_t tile_of_pixel(uint32_t pixel, uint32_t resx, uint32_t tiles_x) { return (pixel / resx / 16u) * tiles_x + (pixel % resx) / 16u; }
@@ -1188,6 +1188,7 @@ struct RecordQueue {
     float2* q2;       // u1, u2
     uint32_t* count;  // records per chunk
     uint4* who;       // parity hook only (ptgpu_guided_capture_records), else NULL: {path id, vertex row, pixel, -} per record
+    float2* q3;       // the directional stochastic filter's two draws (dtree.rs:232), else NULL
 };
 
 __global__ __launch_bounds__(kBlock, PT_SCAN_WAVES) void k_guide_scan(SceneDev sc, RenderParams rp, GuidedParams gp, RecordQueue rq, uint32_t n_paths, uint32_t first_chunk, uint32_t end_chunk) {
@@ -1241,7 +1242,7 @@ __global__ __launch_bounds__(kBlock, PT_SCAN_WAVES) void k_guide_scan(SceneDev s
 #pragma unroll
             for (uint32_t k = 0; k < 8; k++) cur[k] = *stage_cell(stage, stage + 4u * 64u, k, lane);  // (read where used: the compiler sinks them)
             const float4 pp = cur[VTX_P_PDF], wi = cur[VTX_WI];
-            float radiance = 0.0f, u0 = 0.0f, u1 = 0.0f, u2 = 0.0f;
+            float radiance = 0.0f, u0 = 0.0f, u1 = 0.0f, u2 = 0.0f, d0 = 0.0f, d1 = 0.0f;
             if (v < nverts) {
                 radiance = spec_average(l) / pp.w;
                 want = isfinite(radiance) && radiance != 0.0f;  // STree::record's early return (stree.rs:102-116)
@@ -1249,6 +1250,10 @@ __global__ __launch_bounds__(kBlock, PT_SCAN_WAVES) void k_guide_scan(SceneDev s
                     u0 = rng_f32(rng);
                     u1 = rng_f32(rng);
                     u2 = rng_f32(rng);
+                }
+                if (want && gp.directional_filter == 2u) {  // ... then DTree::record_stochastic's two (dtree.rs:232), by the same sampler
+                    d0 = rng_f32(rng);
+                    d1 = rng_f32(rng);
                 }
                 l = l * spec_from(cur[VTX_F0], cur[VTX_F1]);
                 if (f2u(wi.w) & 2u) l = l + spec_from(cur[VTX_LI0], cur[VTX_LI1]);  // fields without their bit were never written
@@ -1265,6 +1270,7 @@ __global__ __launch_bounds__(kBlock, PT_SCAN_WAVES) void k_guide_scan(SceneDev s
                     rq.q1[slot] = make_float4(wi.x, wi.y, wi.z, u0);
                     rq.q2[slot] = make_float2(u1, u2);
                     if (rq.who) rq.who[slot] = make_uint4(pid, v, rp4.z, 0u);
+                    if (rq.q3) rq.q3[slot] = make_float2(d0, d1);
                 }
             }
         }
@@ -1435,6 +1441,7 @@ struct RecordBins {
     uint32_t* count;   // per leaf (zeroed per batch)
     uint32_t* start;   // n_leaves + 1 (exclusive scan of count)
     float4* grouped;   // {sq.x, sq.y, radiance, bits(leaf)} in leaf order
+    float2* grouped2;  // the directional stochastic filter's draws in the same order, else NULL
 };
 // One WAVE per workgroup: a batch brings a leaf ~10^3 records (fewer as the tree grows), and with one wave per leaf run
 // neither do 256 threads share a run of a few hundred records nor do waves wait for one another at barriers.
@@ -1509,7 +1516,9 @@ __global__ __launch_bounds__(kBlock) void k_guide_scatter(GuidedParams gp, Recor
         for (uint32_t j = threadIdx.x; j < n; j += kBlock) {
             const float4 r = rq.q0[base + j];
             const uint32_t pos = f2u(rq.q2[base + j].x);
-            bins.grouped[(size_t)bins.start[f2u(r.w)] + pos] = r;
+            const size_t at = (size_t)bins.start[f2u(r.w)] + pos;
+            bins.grouped[at] = r;
+            if (bins.grouped2) bins.grouped2[at] = rq.q3[base + j];
         }
     }
 }
@@ -1604,7 +1613,26 @@ PT_D void dtree_record_nearest_lane(const uint2* links_of, float* sums_of, V2 p,
     }
 }
 
-__global__ __launch_bounds__(kBinBlock) void k_guide_splat_bins(SdTreeDev tree, RecordBins bins, uint32_t per_block, uint2* spill_base, uint32_t nearest) {
+// DTree::record with the stochastic filter (dtree.rs:223-234): the point jittered inside a box of its leaf cell's size
+// around it (two draws), clipped to the unit square, then recorded by the nearest filter.
+template <bool LDS_TREE>
+PT_D void dtree_record_stochastic_lane(const uint2* links_of, float* sums_of, V2 p, float radiance, float d0, float d1) {
+    Cell cell{0, 0, 0};  // DTree::leaf (dtree.rs:81-94): the cell that holds p
+    uint32_t ni = 0;
+    for (;;) {
+        Cell child;
+        const int c = cell_child_of(cell, p, child);
+        const uint32_t link = child_link(links_of[ni], c);
+        cell = child;
+        if (link == 0 || child.level >= kMaxQuadLevel) break;
+        ni = link;
+    }
+    const Box2 jitter = box2_around(p, box2_extent(cell_box(cell)));
+    const V2 q = jitter.lo + V2{d0, d1} * box2_extent(jitter);                        // Bounds2::lerp
+    dtree_record_nearest_lane<LDS_TREE>(links_of, sums_of, clamp2(q, V2{0.0f, 0.0f}, V2{1.0f, 1.0f}), radiance);  // Bounds2::unit().clip
+}
+
+__global__ __launch_bounds__(kBinBlock) void k_guide_splat_bins(SdTreeDev tree, RecordBins bins, uint32_t per_block, uint2* spill_base, uint32_t filter) {
     __shared__ uint2 sm_links[kBinTreeCap];
     __shared__ float sm_sums[4 * kBinTreeCap];
     __shared__ float sm_lazy[4 * kBinTreeCap];
@@ -1627,8 +1655,11 @@ __global__ __launch_bounds__(kBinBlock) void k_guide_splat_bins(SdTreeDev tree, 
                 __syncthreads();
                 for (uint32_t j = pos + threadIdx.x; j < run_end; j += kBinBlock) {
                     const float4 r = bins.grouped[j];
-                    if (nearest) dtree_record_nearest_lane<true>(sm_links, sm_sums, V2{r.x, r.y}, r.z);
-                    else dtree_record_box_lane<true>(sm_links, sm_sums, sm_lazy, V2{r.x, r.y}, r.z, sm_stack + threadIdx.x, spill, spill_stride);
+                    if (filter == 0u) dtree_record_nearest_lane<true>(sm_links, sm_sums, V2{r.x, r.y}, r.z);
+                    else if (filter == 2u) {
+                        const float2 d = bins.grouped2[j];
+                        dtree_record_stochastic_lane<true>(sm_links, sm_sums, V2{r.x, r.y}, r.z, d.x, d.y);
+                    } else dtree_record_box_lane<true>(sm_links, sm_sums, sm_lazy, V2{r.x, r.y}, r.z, sm_stack + threadIdx.x, spill, spill_stride);
                 }
                 __syncthreads();
                 for (uint32_t k = threadIdx.x; k < 4 * n_nodes; k += kBinBlock) {
@@ -1640,8 +1671,11 @@ __global__ __launch_bounds__(kBinBlock) void k_guide_splat_bins(SdTreeDev tree, 
             } else {
                 for (uint32_t j = pos + threadIdx.x; j < run_end; j += kBinBlock) {
                     const float4 r = bins.grouped[j];
-                    if (nearest) dtree_record_nearest_lane<false>(tree.c_child + c_off, sums_hbm, V2{r.x, r.y}, r.z);
-                    else dtree_record_box_lane<false>(tree.c_child + c_off, sums_hbm, lazy_hbm, V2{r.x, r.y}, r.z, sm_stack + threadIdx.x, spill, spill_stride);
+                    if (filter == 0u) dtree_record_nearest_lane<false>(tree.c_child + c_off, sums_hbm, V2{r.x, r.y}, r.z);
+                    else if (filter == 2u) {
+                        const float2 d = bins.grouped2[j];
+                        dtree_record_stochastic_lane<false>(tree.c_child + c_off, sums_hbm, V2{r.x, r.y}, r.z, d.x, d.y);
+                    } else dtree_record_box_lane<false>(tree.c_child + c_off, sums_hbm, lazy_hbm, V2{r.x, r.y}, r.z, sm_stack + threadIdx.x, spill, spill_stride);
                 }
             }
             if (threadIdx.x == 0) unsafeAtomicAdd(tree.c_weight + leaf_id, (float)(run_end - pos));  // DTree::record: weight += 1 per record

@@ -273,6 +273,8 @@ PARSER_FILTERS = (pt.FILTER_STOCHASTIC, pt.FILTER_BOX)   # what the reference's 
     ("cornell-box-guided", (64, 64), 63, 8, 200.0, (pt.FILTER_NEAREST, pt.FILTER_BOX)),
     ("cornell-box-guided", (64, 64), 63, 8, 200.0, (pt.FILTER_STOCHASTIC, pt.FILTER_NEAREST)),
     ("cornell-box-guided", (64, 64), 63, 8, 200.0, (pt.FILTER_NEAREST, pt.FILTER_NEAREST)),
+    ("cornell-box-guided", (64, 64), 63, 8, 200.0, (pt.FILTER_STOCHASTIC, pt.FILTER_STOCHASTIC)),   # five draws per record (dtree.rs:223-234)
+    ("cornell-box-guided", (64, 64), 63, 8, 200.0, (pt.FILTER_NEAREST, pt.FILTER_STOCHASTIC)),
 ])
 def test_guided_render_in_lock_step_with_oracle(gpu_ctx, name, res, spp, depth, thr, filters):
     """(iv): wave by wave from the same sampling tree; the image of the last wave pixel by pixel."""
@@ -330,6 +332,9 @@ def test_guided_render_in_lock_step_with_oracle(gpu_ctx, name, res, spp, depth, 
                 assert rel_leaf.max() < 2e-3, (w, rel_leaf)
             print(f"wave {w}: per-leaf collector sums, {int(heavy.sum())} leaves of weight >= 50: within 1e-3 {(rel_leaf <= 1e-3).mean():.4f}, "
                   f"median {np.median(rel_leaf):.2e}, worst {rel_leaf.max():.2e}")
+        # node by node as well (L1 distance of all collector sums; the parser's filters are pinned cell by cell by test (ii))
+        gc, wc = got["c_rad"].astype(np.float64), want["c_rad"].astype(np.float64)
+        assert np.abs(gc - wc).sum() <= 5e-3 * np.abs(wc).sum(), (w, np.abs(gc - wc).sum() / np.abs(wc).sum())
         # both refine from the GPU's statistics
         O.close()
         O = ob.OracleSdTree.from_arrays(t, thr, filters)
