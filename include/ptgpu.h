@@ -83,8 +83,9 @@ typedef struct ptgpu_integrator_desc {
     float spatial_threshold;     /* guided: `spatial_threashold` */
     float directional_threshold; /* guided: carried for fidelity; render uses 0.01 like path_guiding/mod.rs:73 */
     int32_t spatial_filter;      /* guided: STOCHASTIC, the only value the reference's parser selects (parser/mod.rs:144;
-                                  * stree.rs:186-201), or NEAREST (stree.rs:117-126). BOX (stree.rs:127-185: one record
-                                  * into every leaf its footprint overlaps) fails with PTGPU_E_INVALID */
+                                  * stree.rs:186-201), NEAREST (stree.rs:117-126) or BOX (stree.rs:127-185: a record goes, in
+                                  * shares of its footprint's volume, to every leaf the footprint overlaps; not with the
+                                  * directional STOCHASTIC filter, whose draws would be per leaf: PTGPU_E_INVALID) */
     int32_t directional_filter;  /* guided: BOX (parser/mod.rs:145; dtree.rs:235-289), NEAREST (dtree.rs:208-222) or
                                   * STOCHASTIC (dtree.rs:223-234: two more draws per record).
                                   * Deviation: a directional quadtree is at most 24 levels deep here (cells of 2^-24; the

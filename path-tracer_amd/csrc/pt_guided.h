@@ -705,7 +705,7 @@ struct GuidedParams {
     uint32_t record;       // 0: the scan only folds the paths into the film (ptgpu_set_final_training(0), last wave)
     uint32_t shard_index, shard_count;
     uint32_t tiles_x, n_tiles;
-    uint32_t spatial_nearest;      // STree filter Nearest instead of Stochastic (stree.rs:117-126): no jitter, no draws
+    uint32_t spatial_filter;       // STree filter: 2 = Stochastic (stree.rs:186-201: three draws per record), 0 = Nearest (stree.rs:117-126), 1 = Box (stree.rs:127-185: k_guide_splat_spatial_box)
     uint32_t directional_filter;   // DTree filter: 1 = Box (dtree.rs:235-289), 0 = Nearest (dtree.rs:208-222), 2 = Stochastic (dtree.rs:223-234: two more draws per record)
 };
 
@@ -1246,7 +1246,7 @@ __global__ __launch_bounds__(kBlock, PT_SCAN_WAVES) void k_guide_scan(SceneDev s
             if (v < nverts) {
                 radiance = spec_average(l) / pp.w;
                 want = isfinite(radiance) && radiance != 0.0f;  // STree::record's early return (stree.rs:102-116)
-                if (want && !gp.spatial_nearest) {  // the stochastic filter's three draws (stree.rs:195-199); the nearest filter draws nothing
+                if (want && gp.spatial_filter == 2u) {  // the stochastic filter's three draws (stree.rs:195-199); the other filters draw nothing
                     u0 = rng_f32(rng);
                     u1 = rng_f32(rng);
                     u2 = rng_f32(rng);
@@ -1468,7 +1468,7 @@ __global__ __launch_bounds__(kBlock) void k_guide_locate(SdTreeDev tree, GuidedP
                 radiance = a.w;
                 sq = dir_to_square(mk3(b.x, b.y, b.z));
                 V3 lo, hi;
-                if (gp.spatial_nearest) leaf_id = stree_leaf<false>(tree, p, lo, hi);  // STree::record_nearest (stree.rs:117-126)
+                if (gp.spatial_filter == 0u) leaf_id = stree_leaf<false>(tree, p, lo, hi);  // STree::record_nearest (stree.rs:117-126)
                 else {
                     (void)stree_leaf<true>(tree, p, lo, hi);
                     const V3 ext = hi - lo;
@@ -1680,6 +1680,76 @@ __global__ __launch_bounds__(kBinBlock) void k_guide_splat_bins(SdTreeDev tree, 
             }
             if (threadIdx.x == 0) unsafeAtomicAdd(tree.c_weight + leaf_id, (float)(run_end - pos));  // DTree::record: weight += 1 per record
             pos = run_end;
+        }
+    }
+}
+
+// STree::record with the BOX spatial filter (stree.rs:127-185): the record goes to every spatial leaf its footprint — a box
+// of the size of p's leaf around p, clamped to the tree's bounds — overlaps, weighted by the share of the footprint's
+// volume; a leaf takes it TWICE, once for each half of its box along its split axis (the reference's recursion halves a
+// leaf like any node before it asks whether it is one). The parser cannot select this filter, so it has no fast path: one
+// lane per record walks the spatial tree (a private stack of node boxes) and splats into the collectors in HBM directly.
+// No draws: the directional filter is box or nearest.
+constexpr int kSpatialBoxStack = 96;
+__global__ __launch_bounds__(kBinBlock) void k_guide_splat_spatial_box(SdTreeDev tree, GuidedParams gp, RecordQueue rq, uint32_t n_paths, uint2* spill_base, uint32_t* guards) {
+    __shared__ uint32_t sm_stack[2 * kBinStackLds * kBinBlock];
+    const size_t spill_stride = (size_t)gridDim.x * kBinBlock;
+    uint2* spill = spill_base + (size_t)blockIdx.x * kBinBlock + threadIdx.x;
+    const uint32_t n_chunks = (n_paths + kBlock - 1) / kBlock;
+    for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+        const uint32_t n = rq.count[chunk];
+        const size_t base = (size_t)chunk * kBlock * gp.n_rows;
+        for (uint32_t j = threadIdx.x; j < n; j += kBinBlock) {
+            const float4 a = rq.q0[base + j], b = rq.q1[base + j];
+            const V3 p = mk3(a.x, a.y, a.z);
+            const float radiance = a.w;
+            const V2 sq = dir_to_square(mk3(b.x, b.y, b.z));
+            V3 lo, hi;
+            (void)stree_leaf<true>(tree, p, lo, hi);
+            const V3 half = (hi - lo) / 2.0f;                                         // Bounds3::around(p, extent)
+            const V3 alo = p - half, ahi = p + half;
+            const V3 flo = clamp3(tree.blo, alo, ahi), fhi = clamp3(tree.bhi, alo, ahi);  // Bounds3::clamp (bounds.rs:100-104)
+            const V3 fe = fhi - flo;
+            const float volume = fe.x * fe.y * fe.z;
+            uint32_t st_node[kSpatialBoxStack];
+            V3 st_lo[kSpatialBoxStack], st_hi[kSpatialBoxStack];
+            int sp = 0;
+            st_node[0] = 0u;
+            st_lo[0] = tree.blo;
+            st_hi[0] = tree.bhi;
+            sp = 1;
+            while (sp > 0) {
+                --sp;
+                const uint32_t ni = st_node[sp];
+                const V3 nlo = st_lo[sp], nhi = st_hi[sp];
+                const uint4 node = tree.snodes[ni];
+                const int ax = (int)node.z;
+                const float mid = (get(nlo, ax) + get(nhi, ax)) / 2.0f;               // centroid()[split_axis]
+                for (int i = 0; i < 2; i++) {
+                    V3 clo = nlo, chi = nhi;
+                    if (i == 0) set(chi, ax, mid);
+                    else set(clo, ax, mid);
+                    const V3 olo = mk3(fmaxf(flo.x, clo.x), fmaxf(flo.y, clo.y), fmaxf(flo.z, clo.z));
+                    const V3 ohi = mk3(fminf(fhi.x, chi.x), fminf(fhi.y, chi.y), fminf(fhi.z, chi.z));
+                    const V3 oe = ohi - olo;
+                    const float overlap = (oe.x <= 0.0f || oe.y <= 0.0f || oe.z <= 0.0f) ? 0.0f : oe.x * oe.y * oe.z;
+                    const float w = overlap / volume;
+                    if (w == 0.0f) continue;
+                    if (node.x == 0u) {  // a leaf: DTree::record(p2, radiance * w, w) (dtree.rs:200-207)
+                        const uint32_t leaf_id = node.w, c_off = tree.leaf_info[leaf_id].y;
+                        float* sums = reinterpret_cast<float*>(tree.c_rad + c_off);
+                        if (gp.directional_filter == 0u) dtree_record_nearest_lane<false>(tree.c_child + c_off, sums, sq, radiance * w);
+                        else dtree_record_box_lane<false>(tree.c_child + c_off, sums, reinterpret_cast<float*>(tree.c_lazy + c_off), sq, radiance * w, sm_stack + threadIdx.x, spill, spill_stride);
+                        unsafeAtomicAdd(tree.c_weight + leaf_id, w);
+                    } else if (sp < kSpatialBoxStack) {
+                        st_node[sp] = i == 0 ? node.x : node.y;
+                        st_lo[sp] = clo;
+                        st_hi[sp] = chi;
+                        sp++;
+                    } else
+                        atomicAdd(guards + kGuardVertexStore, 1u);  // (a spatial tree deeper than the walk's stack: counted, never seen)
+                }
+            }
         }
     }
 }

@@ -79,7 +79,8 @@ struct SceneDev {
 };
 // Limits the reference does not have; each is counted when it actually changes a result, so tests can assert "never".
 enum { kGuardPassThrough = 0,   // a path ended after kMaxPassThrough consecutive pass-through crossings (pt_state.h)
-       kGuardVertexStore = 1,   // a guided path vertex beyond the vertex store's rows was dropped (cannot happen: rows = max_depth + 1)
+       kGuardVertexStore = 1,   // a guided path vertex beyond the vertex store's rows was dropped (cannot happen: rows = max_depth + 1), or a
+                                // subtree beyond the walk stack of the spatial box filter (pt_guided.h: k_guide_splat_spatial_box; 96 levels)
        kGuardQuadLevel = 2,     // the refinement declined to split a quadtree cell at level kMaxQuadLevel (pt_guided.h)
        kGuardNonFinite = 3,     // a sample whose radiance is not finite was dropped instead of added to the film (pt_kernels.h: film_add_rgb_wave)
        kNumGuards = 4 };

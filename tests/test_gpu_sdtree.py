@@ -275,6 +275,9 @@ PARSER_FILTERS = (pt.FILTER_STOCHASTIC, pt.FILTER_BOX)   # what the reference's 
     ("cornell-box-guided", (64, 64), 63, 8, 200.0, (pt.FILTER_NEAREST, pt.FILTER_NEAREST)),
     ("cornell-box-guided", (64, 64), 63, 8, 200.0, (pt.FILTER_STOCHASTIC, pt.FILTER_STOCHASTIC)),   # five draws per record (dtree.rs:223-234)
     ("cornell-box-guided", (64, 64), 63, 8, 200.0, (pt.FILTER_NEAREST, pt.FILTER_STOCHASTIC)),
+    # the spatial box filter (stree.rs:127-185): a record goes, in shares, to every leaf its footprint overlaps
+    ("cornell-box-guided", (64, 64), 63, 8, 200.0, (pt.FILTER_BOX, pt.FILTER_BOX)),
+    ("cornell-box-guided", (64, 64), 63, 8, 200.0, (pt.FILTER_BOX, pt.FILTER_NEAREST)),
 ])
 def test_guided_render_in_lock_step_with_oracle(gpu_ctx, name, res, spp, depth, thr, filters):
     """(iv): wave by wave from the same sampling tree; the image of the last wave pixel by pixel."""
@@ -294,7 +297,8 @@ def test_guided_render_in_lock_step_with_oracle(gpu_ctx, name, res, spp, depth, 
     extent = float((o.info()["bounds"][3:] - o.info()["bounds"][:3]).max())
     compared = 0
     for w, n_passes in enumerate(waves):
-        check_records = w in (1, 3)
+        # (the box filter has no single leaf per record: neither side logs its records; the collectors below see all of them)
+        check_records = w in (1, 3) and filters[0] != pt.FILTER_BOX
         gpu_ctx.guided_capture_records(check_records)
         O.log_records(check_records)
         gpu_ctx.guided_wave(w)
@@ -343,7 +347,7 @@ def test_guided_render_in_lock_step_with_oracle(gpu_ctx, name, res, spp, depth, 
             O.new_iteration(w)
             assert_same_tree(ob.canonical(gpu_ctx.guided_tree(), thr), O.export())
     gpu_ctx.guided_capture_records(False)
-    assert compared == 2
+    assert compared == (0 if filters[0] == pt.FILTER_BOX else 2)
     gf, gs, gst = gpu_ctx.guided_end()
     assert gs == 1.0 / waves[-1]
     g, c = gf * gs, film_o * gs
