@@ -20,6 +20,10 @@ namespace pt {
 #ifndef PT_PATH_DIFFUSE_WAVES
 #define PT_PATH_DIFFUSE_WAVES 3  // k_shade_path without conductors: 3 waves per SIMD fit (171 registers otherwise, one too many)
 #endif
+#ifndef PT_PATH_CONDUCTOR_WAVES
+#define PT_PATH_CONDUCTOR_WAVES 3  // k_shade_path with conductors: 213 registers at 2 waves; at 3 it spills 160 B per lane and is still faster
+                                   // (veach-bidir shade 17.9 -> 16.4 ms per 64 spp, veach-mis 21.9 -> 21.8; k_shade_guided loses: 5.7 -> 6.4)
+#endif
 
 // One atomic per wave: lanes with `want` get consecutive indices from *counter.
 PT_D uint32_t wave_alloc(uint32_t* counter, bool want) {
@@ -430,7 +434,7 @@ PT_D void stage_small_scene(const SceneDev& sc, Lds& sm) {  // every thread of t
 // ------------------------------------------------------------------ shade: `path` integrator
 // One iteration of PathIntegrator::li's loop body after the intersection (path_tracer.rs:69-180).
 template <int KINDS, bool SMALL>
-__global__ __launch_bounds__(kBlock, KINDS != 7 ? PT_PATH_DIFFUSE_WAVES : PT_SHADE_WAVES) void k_shade_path(SceneDev sc, RenderParams rp, PathCols in, HitCols hit, PathCols out, ShadowCols sh,
+__global__ __launch_bounds__(kBlock, KINDS != 7 ? PT_PATH_DIFFUSE_WAVES : PT_PATH_CONDUCTOR_WAVES) void k_shade_path(SceneDev sc, RenderParams rp, PathCols in, HitCols hit, PathCols out, ShadowCols sh,
                                                        const RoundCounters* cur, RoundCounters* nxt) {
     __shared__ BlockAlloc sm_alloc;
     __shared__ uint32_t sm_count;
