@@ -383,11 +383,16 @@ struct STree {
         V3 q = bounds.clip(jitter.lerp(v3(u0, u1, u2)));
         return record_nearest(q, p2, radiance, sampler);
     }
-    // STree::record (stree.rs:102-116) with the stochastic filter's draws supplied by the caller
+    // STree::record (stree.rs:102-116) with the stochastic filter's draws supplied by the caller (the other filters draw nothing)
     void record_drawn(V3 p, V3 wi, float radiance, float u0, float u1, float u2, Sampler& sampler) {
         if (!std::isfinite(radiance)) return;
         if (radiance == 0.0f) return;
-        record_stochastic_drawn(p, dir_to_square(wi), radiance, u0, u1, u2, sampler);
+        V2 p2 = dir_to_square(wi);
+        switch (filter) {
+            case Filter::Nearest: record_nearest(p, p2, radiance, sampler); break;
+            case Filter::Box: record_box(p, p2, radiance, sampler); break;
+            case Filter::Stochastic: record_stochastic_drawn(p, p2, radiance, u0, u1, u2, sampler); break;
+        }
     }
     void record(V3 p, V3 wi, float radiance, Sampler& sampler) {  // stree.rs:102-116
         if (!std::isfinite(radiance)) return;

@@ -1,4 +1,4 @@
-"""Seeded fuzzing of the bit-exact links of the path (needs an MI355X): random triangle soups of random sizes and
+"""Seeded fuzzing of the bit-exact links of the path and of its record pass (needs an MI355X): random triangle soups of random sizes and
 scales through both BVH builders (host, device) and both walks (binary, four-wide), closest hits and occlusion against
 the CPU oracle, bit for bit (bvh.rs:86-304, geom.rs:180-262). The default is a handful of seeds (seconds);
 PT_FUZZ_SEEDS=<n> runs n of them, PT_FUZZ_FIRST=<k> starts at seed k (the round-3 pass: 300 seeds, profiles/r03k_fuzz.log)."""
@@ -111,3 +111,70 @@ def test_fuzzed_statistics_refine_like_the_oracle(gpu_ctx, seed):
     film, scale, st = gpu_ctx.guided_end()
     assert np.isfinite(film).all() and st["samples"] == 32 * 16 * 63
     assert gpu_ctx.guard_counts() == guards_before
+
+
+RECORD_FILTERS = [(s, d) for s in (pt.FILTER_STOCHASTIC, pt.FILTER_NEAREST, pt.FILTER_BOX) for d in (pt.FILTER_BOX, pt.FILTER_NEAREST)]
+
+
+@pytest.mark.parametrize("seed", range(FIRST, FIRST + SEEDS))
+def test_fuzzed_records_land_where_the_oracle_puts_them(gpu_ctx, seed):
+    """STree::record / DTree::record (stree.rs:102-201, dtree.rs:200-289) through the production record pass on made-up
+    records, for the six filter pairs a record with three draws can drive: the tree of a short render, its collectors
+    emptied, then one batch of random records (points on the scene's surfaces, in its volume and, where the filter
+    clips or descends blindly, outside its bounds; log-normal radiance) on both sides. Leaf weights are equal exactly
+    where a record goes to one leaf, every collector cell to f32 summation order."""
+    from test_gpu_sdtree import assert_same_tree, surface_points
+    rng = np.random.default_rng(seed)
+    filters = RECORD_FILTERS[seed % len(RECORD_FILTERS)]
+    thr = float(10.0 ** rng.uniform(1.0, 2.3))
+    sc = pt.LoadedScene("cornell-box-guided", resx=48, resy=48, max_depth=6)
+    o = ob.OracleScene(sc)
+    gpu_ctx.load(sc)
+    integ = pt.IntegratorDesc.from_buffer_copy(sc.integrator)
+    integ.spatial_threshold = thr
+    integ.spatial_filter, integ.directional_filter = filters
+    n_waves = gpu_ctx.guided_begin(integ, 31)
+    trained = int(rng.integers(2, n_waves))
+    for w in range(trained):
+        gpu_ctx.guided_wave(w)
+    t0 = gpu_ctx.guided_tree()
+    _, count = gpu_ctx.guided_stats()
+    gpu_ctx.guided_stats_set(np.zeros(count, dtype=np.float32))
+    t0["c_rad"][:] = 0
+    t0["c_weight"][:] = 0
+    O = ob.OracleSdTree.from_arrays(t0, thr, filters)
+    n = int(rng.integers(2000, 60000))
+    lo, hi = t0["bounds"][:3], t0["bounds"][3:]
+    inside = rng.uniform(lo, hi, (n // 4, 3)).astype(np.float32)
+    outside = rng.uniform(lo - 0.2 * (hi - lo), hi + 0.2 * (hi - lo), (n // 8, 3)).astype(np.float32)
+    # (the box filter's footprint of a point outside the tree has no volume: 0 / 0 on both sides, nothing to compare)
+    p = np.concatenate([surface_points(o, rng, n), inside] + ([] if filters[0] == pt.FILTER_BOX else [outside]))
+    wi = rng.normal(size=(len(p), 3)).astype(np.float32)
+    wi /= np.linalg.norm(wi, axis=1, keepdims=True).astype(np.float32)
+    zero2 = np.zeros((len(wi), 2), dtype=np.float32)
+    same = (gpu_ctx.guided_probe(wi, zero2)[:, 14:16] == O.probe(wi, zero2)[:, 14:16]).all(axis=1)   # directions both atan2f agree on (test (ii))
+    assert same.mean() > 0.7
+    p, wi = p[same], wi[same]
+    rad = np.exp(rng.normal(0.0, 2.0, len(p))).astype(np.float32)
+    rec = np.concatenate([p, wi, rad[:, None], rng.random((len(p), 3)).astype(np.float32)], axis=1).astype(np.float32)
+    gpu_ctx.guided_record_batch(rec)
+    O.record(rec)
+    got, want = ob.canonical(gpu_ctx.guided_tree(), thr), O.export()
+    O.close()
+    assert_same_tree(got, want, sums=False)
+    gw, ww = got["c_weight"].astype(np.float64), want["c_weight"].astype(np.float64)
+    if filters[0] == pt.FILTER_BOX:   # shares of a record's footprint: sums of fractions, in another order
+        assert abs(gw.sum() / ww.sum() - 1.0) < 1e-5 and np.abs(gw - ww).max() <= 1e-4 * max(1.0, ww.max()), (filters, np.abs(gw - ww).max())
+    else:
+        assert (gw == ww).all() and ww.sum() == len(rec), filters
+    a, b = got["c_rad"].astype(np.float64), want["c_rad"].astype(np.float64)
+    assert abs(a.sum() / b.sum() - 1.0) < 1e-5, (filters, a.sum(), b.sum())
+    touched = b > 0
+    assert not a[~touched].any()
+    # per cell: the same terms in another order (a cell that received k terms is off by ~sqrt(k) * 2^-24 of its largest term)
+    scale = np.maximum(b, 1e-3 * b.max())
+    assert (np.abs(a - b)[touched] / scale[touched]).max() < 2e-5, (filters, (np.abs(a - b)[touched] / scale[touched]).max())
+    for w in range(trained, n_waves):
+        gpu_ctx.guided_wave(w)
+    film, _, st = gpu_ctx.guided_end()
+    assert np.isfinite(film).all()
