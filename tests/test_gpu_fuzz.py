@@ -1,7 +1,8 @@
 """Seeded fuzzing of the bit-exact links of the path and of its record pass (needs an MI355X): random triangle soups of random sizes and
 scales through both BVH builders (host, device) and both walks (binary, four-wide), closest hits and occlusion against
-the CPU oracle, bit for bit (bvh.rs:86-304, geom.rs:180-262). The default is a handful of seeds (seconds);
-PT_FUZZ_SEEDS=<n> runs n of them, PT_FUZZ_FIRST=<k> starts at seed k (the round-3 pass: 300 seeds, profiles/r03k_fuzz.log)."""
+the CPU oracle, bit for bit (bvh.rs:86-304, geom.rs:180-262); device refinements from made-up statistics; made-up record batches
+under six filter pairs; renders of made-up scenes. The default is a handful of seeds (seconds);
+PT_FUZZ_SEEDS=<n> runs n of them, PT_FUZZ_FIRST=<k> starts at seed k (the round-3 passes: 200-300 seeds each, profiles/r03k_fuzz.log)."""
 import os
 
 import numpy as np
@@ -178,3 +179,72 @@ def test_fuzzed_records_land_where_the_oracle_puts_them(gpu_ctx, seed):
         gpu_ctx.guided_wave(w)
     film, _, st = gpu_ctx.guided_end()
     assert np.isfinite(film).all()
+
+
+def random_spectrum(rng, lo, hi):
+    """A sigmoid-polynomial spectrum (spectrum/rgb2spec.rs: s(c0 l^2 + c1 l + c2) * scale) with coefficients of the size the
+    coefficient table holds, scaled into [lo, hi]."""
+    return (float(rng.normal(0.0, 3e-5)), float(rng.normal(0.0, 0.03)), float(rng.normal(0.0, 3.0)), float(rng.uniform(lo, hi)))
+
+
+def random_scene(rng):
+    """A soup around the camera (at the origin, looking down +z) with every kind of surface the path knows: diffuse,
+    dielectric (eta on either side of 1), smooth and rough conductors, surfaces without a material, one or two emitters."""
+    mats = [(pt.MAT_LAMBERTIAN, 0.0, random_spectrum(rng, 0.2, 1.0), (0, 0, 0, 0)),
+            (pt.MAT_DIELECTRIC, 0.0, (0.0, 0.0, 0.0, float(rng.choice([1.0, 1.6, 2.0, 2.6, 3.0, 4.0]))), (0, 0, 0, 0)),   # Constant eta = scale / 2
+            (pt.MAT_CONDUCTOR, float(rng.choice([0.0, 5e-5, 0.01, 0.1, 0.5, 1.0])), random_spectrum(rng, 0.2, 3.0), random_spectrum(rng, 1.0, 6.0)),
+            (pt.MAT_CONDUCTOR, float(rng.uniform(0.001, 0.6)), random_spectrum(rng, 0.2, 3.0), random_spectrum(rng, 1.0, 6.0)),
+            (pt.MAT_LAMBERTIAN, 0.0, random_spectrum(rng, 0.0, 0.5), (0, 0, 0, 0))]
+    meshes = []
+    n_meshes = int(rng.integers(3, 9))
+    for m in range(n_meshes):
+        k = int(rng.integers(4, 120))
+        centers = rng.uniform(-4.0, 4.0, size=(k, 1, 3))
+        pts = (centers + rng.normal(0, rng.uniform(0.3, 1.5), size=(k, 3, 3))).reshape(-1, 3).astype(np.float32)
+        tris = np.arange(3 * k, dtype=np.uint32).reshape(k, 3)
+        for i in range(1, k, 2):
+            tris[i, 0] = tris[i - 1, 1]
+            tris[i, 1] = tris[i - 1, 2]
+        mesh = {"points": pts, "triangles": tris, "material_index": int(rng.integers(-1, len(mats)))}
+        if rng.random() < 0.5:   # smooth shading normals (scene.rs:196-204 interpolates and renormalises them)
+            nrm = rng.normal(size=pts.shape).astype(np.float32)
+            mesh["normals"] = nrm / np.linalg.norm(nrm, axis=1, keepdims=True).astype(np.float32)
+        if m < 2 and (m == 0 or rng.random() < 0.5):
+            mesh["emission"] = random_spectrum(rng, 0.5, 20.0)
+            mesh["material_index"] = max(mesh["material_index"], 0) if rng.random() < 0.8 else mesh["material_index"]
+        meshes.append(mesh)
+    return pt.SceneDescription(meshes, mats)
+
+
+@pytest.mark.parametrize("seed", range(FIRST, FIRST + SEEDS))
+def test_fuzzed_scenes_render_path_for_path(gpu_ctx, seed):
+    """`path` (PT / NEE / MIS) and `lightpath` on made-up scenes — every BSDF, surfaces without a material, shading normals,
+    ragged image sizes, depths from 1 to 12 — against the oracle with the same per-(pixel, sample) streams: the same
+    paths, so the images agree pixel by pixel and the ray counts (almost) to the ray; `guided` for its first wave, which
+    has no tree yet (mod.rs:70-122)."""
+    rng = np.random.default_rng(seed)
+    sc = random_scene(rng)
+    o = ob.OracleScene(sc)
+    gpu_ctx.set_scene(sc)
+    cam = pt.make_camera(su.IDENTITY, float(rng.uniform(20.0, 120.0)), int(rng.integers(5, 70)), int(rng.integers(5, 70)))
+    gpu_ctx.set_camera(cam)
+    import warnings
+    for kind in (pt.INTEGRATOR_PATH, pt.INTEGRATOR_LIGHTPATH, pt.INTEGRATOR_GUIDED):
+        integ = pt.make_integrator(kind, int(rng.integers(1, 13)), int(rng.choice([pt.MODE_PT, pt.MODE_NEE, pt.MODE_MIS])))
+        spp = 1 if kind == pt.INTEGRATOR_GUIDED else int(rng.integers(1, 24))
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")   # a non-finite sample is reported by both sides (compared below), not an error here
+            gf, gs, gst = gpu_ctx.render(integ, spp)
+            cf, cs, cst = o.render(cam, integ, spp)
+        assert gs == cs
+        what = (seed, kind, integ.max_depth, integ.mode, spp)
+        for k in ("samples", "extend_rays", "shadow_rays", "segments"):
+            # (a path that a last-ulp libm difference re-routes adds or removes up to max_depth rays of each kind)
+            assert abs(gst[k] - cst[k]) <= 2e-4 * cst[k] + 2 * (integ.max_depth + 1) + 4, (what, k, gst[k], cst[k])
+        assert np.isfinite(gf).all() and np.isfinite(cf).all(), what
+        g, c = gf * gs, cf * cs
+        rel = np.abs(g - c).sum(axis=2) / (np.abs(c).sum(axis=2) + 1e-6)
+        assert np.median(rel) < 1e-5, (what, np.median(rel))
+        assert (rel < 1e-3).mean() > 0.98, (what, (rel < 1e-3).mean())
+        assert abs(g.sum() - c.sum()) <= 2e-3 * abs(c.sum()) + 1e-6, (what, g.sum(), c.sum())
+        print(f"seed {seed} integrator {kind} depth {integ.max_depth} mode {integ.mode} spp {spp} {cam.resx}x{cam.resy}: mean {c.mean():.4g}, lit pixels {(c.sum(axis=2) > 0).mean():.2f}, rays {cst['extend_rays']} + {cst['shadow_rays']}, pixels within 1e-3 {(rel < 1e-3).mean():.4f}")
