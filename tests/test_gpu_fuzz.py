@@ -311,3 +311,43 @@ def test_fuzzed_scenes_guided_in_lock_step(gpu_ctx, seed):
     assert np.median(rel) < 1e-5 and (rel < 1e-3).mean() > 0.97, (what, np.median(rel), (rel < 1e-3).mean())
     print(f"seed {seed} filters {filters} threshold {thr:.1f} depth {depth} spp {spp} {cam.resx}x{cam.resy}: {n_spatial} spatial nodes, {len(t['c_rad'])} quadtree nodes, "
           f"lit pixels {(c.sum(axis=2) > 0).mean():.2f}, pixels within 1e-3 {(rel < 1e-3).mean():.4f}")
+
+
+@pytest.mark.parametrize("seed", range(FIRST, FIRST + SEEDS))
+def test_fuzzed_scenes_render_the_same_however_the_work_is_cut(gpu_ctx, seed):
+    """What the multi-GPU driver and the batch fallback rely on: every (pixel, sample) has its own stream, so the shards of a
+    made-up job (sample index mod n, ptgpu_render_shard), its batches of any size, either traversal and either BVH builder
+    give the film of the one-piece render, up to f64 add order."""
+    rng = np.random.default_rng(seed)
+    sc = random_scene(rng)
+    cam = pt.make_camera(su.IDENTITY, float(rng.uniform(20.0, 120.0)), int(rng.integers(5, 70)), int(rng.integers(5, 70)))
+    kind = int(rng.choice([pt.INTEGRATOR_PATH, pt.INTEGRATOR_LIGHTPATH]))
+    integ = pt.make_integrator(kind, int(rng.integers(1, 13)), int(rng.choice([pt.MODE_PT, pt.MODE_NEE, pt.MODE_MIS])))
+    spp = int(rng.integers(2, 24))
+    import warnings
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            gpu_ctx.set_bvh_builder(0)
+            gpu_ctx.set_scene(sc)
+            gpu_ctx.set_camera(cam)
+            whole, scale, st = gpu_ctx.render(integ, spp)
+            n = int(rng.integers(2, 6))
+            parts = [gpu_ctx.render(integ, spp, k, n) for k in range(n)]
+            assert np.allclose(sum(p[0] for p in parts), whole, rtol=1e-9, atol=1e-12), (seed, "shards", n)
+            assert sum(p[2]["samples"] for p in parts) == st["samples"] and sum(p[2]["extend_rays"] for p in parts) == st["extend_rays"]
+            gpu_ctx.set_batch_paths(int(rng.integers(1, 4)) * cam.resx * cam.resy)
+            small, _, st2 = gpu_ctx.render(integ, spp)
+            gpu_ctx.set_batch_paths(0)
+            assert np.allclose(small, whole, rtol=1e-9, atol=1e-12) and st2["extend_rays"] == st["extend_rays"], (seed, "batches")
+            gpu_ctx.set_traversal(True)
+            wide, _, st3 = gpu_ctx.render(integ, spp)
+            assert np.allclose(wide, whole, rtol=1e-9, atol=1e-12) and st3["shadow_rays"] == st["shadow_rays"], (seed, "four-wide walk")
+            gpu_ctx.set_bvh_builder(1)
+            gpu_ctx.set_scene(sc)
+            gpu_ctx.set_camera(cam)
+            dev, _, st4 = gpu_ctx.render(integ, spp)
+            assert np.allclose(dev, whole, rtol=1e-9, atol=1e-12) and st4["segments"] == st["segments"], (seed, "device-built BVH")
+    finally:
+        gpu_ctx.set_batch_paths(0)
+        gpu_ctx.set_bvh_builder(2)
