@@ -1,7 +1,8 @@
 """Seeded fuzzing of the bit-exact links of the path and of its record pass (needs an MI355X): random triangle soups of random sizes and
 scales through both BVH builders (host, device) and both walks (binary, four-wide), closest hits and occlusion against
 the CPU oracle, bit for bit (bvh.rs:86-304, geom.rs:180-262); device refinements from made-up statistics; made-up record batches
-under six filter pairs; renders of made-up scenes. The default is a handful of seeds (seconds);
+under six filter pairs; renders of made-up scenes path for path, `guided` wave by wave in lock step, and cut into shards and
+batches. The default is a handful of seeds (seconds);
 PT_FUZZ_SEEDS=<n> runs n of them, PT_FUZZ_FIRST=<k> starts at seed k (the round-3 passes: 200-300 seeds each, profiles/r03k_fuzz.log)."""
 import os
 
