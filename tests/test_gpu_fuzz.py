@@ -31,18 +31,20 @@ def fuzz_ctx(gpu_ctx):
         pass
 
 
-def soup_of(rng):
+def soup_of(rng, largest=6000.0, smallest=1.0):
     """Sizes from one triangle to a few thousand, extents over six decades, triangle sizes from slivers to scene-sized."""
-    n_tris = int(np.exp(rng.uniform(0.0, np.log(6000.0))))
+    n_tris = int(np.exp(rng.uniform(np.log(smallest), np.log(largest))))
     extent = float(10.0 ** rng.uniform(-2.0, 4.0))
     size = extent * float(10.0 ** rng.uniform(-2.5, 0.0))
     return su.random_soup(rng, n_tris, n_meshes=int(rng.integers(1, min(4, n_tris) + 1)), extent=extent, size=size)
 
 
-@pytest.mark.parametrize("seed", range(FIRST, FIRST + SEEDS))
-def test_fuzzed_soups_hit_for_hit(fuzz_ctx, seed):
-    rng = np.random.default_rng(seed)
-    sc = soup_of(rng)
+@pytest.mark.parametrize("seed,big", [(s, False) for s in range(FIRST, FIRST + SEEDS)] + [(s, True) for s in range(FIRST, FIRST + max(1, SEEDS // 6))])
+def test_fuzzed_soups_hit_for_hit(fuzz_ctx, seed, big):
+    """big: 16 384 to 150 000 triangles — where the library's own choice is the device builder and, from 256 KB of nodes, the
+    four-wide walk with its nodes in HBM."""
+    rng = np.random.default_rng(seed + (500000 if big else 0))
+    sc = soup_of(rng, 150000.0, 16384.0) if big else soup_of(rng)
     o = ob.OracleScene(sc)
     on, ol = o.bvh()
     info = o.info()
