@@ -354,3 +354,73 @@ def test_fuzzed_scenes_render_the_same_however_the_work_is_cut(gpu_ctx, seed):
     finally:
         gpu_ctx.set_batch_paths(0)
         gpu_ctx.set_bvh_builder(2)
+
+
+@pytest.mark.parametrize("seed", range(FIRST, FIRST + max(1, SEEDS // 2)))
+def test_fuzzed_scenes_guided_shards_in_lock_step(gpu_ctx, seed):
+    """The multi-GPU protocol of `guided` on made-up scenes, two or three ranks as contexts on one GPU, every rank against the
+    oracle tracing the same shard — the (pass, tile) pairs with (tile + pass) % n == rank — of the same wave from the same
+    tree: per-rank collectors, then the summed statistics written to every rank (what the in-place all-reduce leaves), the
+    same next generation on every rank and in the oracle, and the sum of the ranks' last-wave films pixel by pixel."""
+    from test_gpu_sdtree import assert_same_tree, waves_of
+    rng = np.random.default_rng(seed)
+    sc = random_scene(rng)
+    o = ob.OracleScene(sc)
+    n = int(rng.integers(2, 4))
+    cam = pt.make_camera(su.IDENTITY, float(rng.uniform(30.0, 110.0)), int(rng.integers(17, 70)), int(rng.integers(17, 70)))   # 2 x 2 to 5 x 5 tiles, ragged
+    filters = GUIDED_FILTERS[seed % len(GUIDED_FILTERS)]
+    thr = float(10.0 ** rng.uniform(0.7, 2.0))
+    depth = int(rng.integers(2, 8))
+    integ = pt.make_integrator(pt.INTEGRATOR_GUIDED, depth, int(rng.choice([pt.MODE_PT, pt.MODE_NEE, pt.MODE_MIS])), thr)
+    integ.spatial_filter, integ.directional_filter = filters
+    spp = int(rng.choice([7, 15]))
+    waves = waves_of(spp)
+    what = (seed, n, filters, thr, depth, integ.mode, spp, cam.resx, cam.resy)
+    ranks = [gpu_ctx] + [pt.Context(0) for _ in range(n - 1)]
+    try:
+        for r, c in enumerate(ranks):
+            c.set_batch_paths(1 << 14)
+            c.set_scene(sc)
+            c.set_camera(cam)
+            assert c.guided_begin(integ, spp, r, n) == len(waves)
+        common, first, films_o = None, 0, None
+        for w, n_passes in enumerate(waves):
+            stats, films_o = [], []
+            for r, c in enumerate(ranks):
+                c.guided_wave(w)
+                t = c.guided_tree()
+                O = ob.OracleSdTree.fresh(o, thr, filters) if common is None else ob.OracleSdTree.from_arrays(common, thr, filters)
+                film_o, st_o = O.wave(o, cam, integ, w, first, n_passes, shard_index=r, shard_count=n)
+                films_o.append(film_o)
+                got, want = ob.canonical(t, thr), O.export()
+                O.close()
+                assert_same_tree(got, want, sums=False)
+                gw, ww = got["c_weight"].astype(np.float64), want["c_weight"].astype(np.float64)
+                assert abs(gw.sum() - ww.sum()) <= 2e-3 * ww.sum() + 2 * (depth + 1), (what, w, r, gw.sum(), ww.sum())
+                if ww.sum() >= 50.0:
+                    gc, wc = got["c_rad"].astype(np.float64), want["c_rad"].astype(np.float64)
+                    assert np.abs(gc - wc).sum() <= 0.1 * np.abs(wc).sum(), (what, w, r)
+                stats.append(c.guided_stats_host())
+            first += n_passes
+            assert len({s.size for s in stats}) == 1, (what, w)          # (a collective over unequal buffers would hang)
+            if w + 1 < len(waves):
+                total = np.sum(stats, axis=0, dtype=np.float32)
+                for c in ranks:
+                    c.guided_stats_set(total)
+                O = ob.OracleSdTree.from_arrays(ranks[0].guided_tree(), thr, filters)
+                O.new_iteration(w)
+                want = O.export()
+                O.close()
+                for c in ranks:
+                    c.guided_refine()
+                    assert_same_tree(ob.canonical(c.guided_tree(), thr), want)
+                common = ranks[0].guided_tree()
+        ends = [c.guided_end() for c in ranks]
+    finally:
+        for c in ranks[1:]:
+            c.close()
+        gpu_ctx.set_batch_paths(0)
+    assert sum(e[2]["samples"] for e in ends) == cam.resx * cam.resy * spp, what   # every sample traced once
+    g, c = sum(e[0] for e in ends) * ends[0][1], sum(films_o) * ends[0][1]
+    rel = np.abs(g - c).sum(axis=2) / (np.abs(c).sum(axis=2) + 1e-6)
+    assert np.median(rel) < 1e-5 and (rel < 1e-3).mean() > 0.97, (what, np.median(rel), (rel < 1e-3).mean())
