@@ -146,9 +146,11 @@ int ptgpu_render_shard(ptgpu_ctx* ctx, const ptgpu_integrator_desc* integrator, 
  * so that a multi-GPU driver can all-reduce the SD-tree statistics between waves:
  *   begin -> for w in 0..n_waves { wave(w); [all-reduce stats in place]; } -> end.
  * ptgpu_guided_stats returns the DEVICE pointer and element count (f32) of the flat collector buffer of the
- * wave just traced: per spatial leaf its DTree node sums (4 per node) followed by one statistical weight.
- * Topology is identical on every shard, so an element-wise sum across GPUs is exactly the single-GPU state
- * up to f32 reassociation. */
+ * wave just traced: the DTree node sums of every spatial leaf (4 per node, leaves in order), then one statistical
+ * weight per leaf. Topology is identical on every shard, so an element-wise sum across GPUs is exactly the
+ * single-GPU state up to f32 reassociation. The buffer is complete when ptgpu_guided_wave returns; the library's
+ * streams are non-blocking (they wait for no other stream, the null stream included), so whoever writes the buffer
+ * completes the write — synchronises the stream the collective ran on — before the next ptgpu call. */
 int ptgpu_guided_begin(ptgpu_ctx* ctx, const ptgpu_integrator_desc* integrator, uint32_t spp, uint32_t shard_index,
                        uint32_t shard_count, uint32_t* n_waves_out);
 int ptgpu_guided_wave(ptgpu_ctx* ctx, uint32_t wave);

@@ -511,6 +511,11 @@ class Context:
         hip = C.CDLL("libamdhip64.so")
         hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
         rc = hip.hipMemcpy(C.c_void_p(ptr), arr.ctypes.data_as(C.c_void_p), C.c_size_t(count * 4), 1)  # hipMemcpyHostToDevice
+        if rc == 0:
+            # a copy from pageable memory on the null stream may return once the data is staged; the library's streams are
+            # non-blocking and would not wait for it: whoever writes the buffer completes the write before the next call
+            # (ptgpu.h: ptgpu_guided_stats), as the multi-GPU driver does after its all-reduce
+            rc = hip.hipDeviceSynchronize()
         if rc != 0:
             raise PtError(f"hipMemcpy into the statistics buffer failed ({rc})")
 
