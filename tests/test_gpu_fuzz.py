@@ -39,7 +39,7 @@ def soup_of(rng, largest=6000.0, smallest=1.0):
     return su.random_soup(rng, n_tris, n_meshes=int(rng.integers(1, min(4, n_tris) + 1)), extent=extent, size=size)
 
 
-@pytest.mark.parametrize("seed,big", [(s, False) for s in range(FIRST, FIRST + SEEDS)] + [(s, True) for s in range(FIRST, FIRST + max(1, SEEDS // 6))])
+@pytest.mark.parametrize("seed,big", [(s, False) for s in range(FIRST, FIRST + SEEDS)] + [(s, True) for s in range(FIRST, FIRST + SEEDS // 12)])   # (big ones: from PT_FUZZ_SEEDS=12 on; 13 s each, most of it the oracle's build)
 def test_fuzzed_soups_hit_for_hit(fuzz_ctx, seed, big):
     """big: 16 384 to 150 000 triangles — where the library's own choice is the device builder and, from 256 KB of nodes, the
     four-wide walk with its nodes in HBM."""
