@@ -938,7 +938,8 @@ namespace {
 // does not (most rays finish inside one round of the while-while loop: nothing to refill, Cornell extend +13 %).
 // PTGPU_STREAM_WALK=0: one ray per lane and trip everywhere.
 bool stream_walk_enabled() {
-    static const bool on = getenv("PTGPU_STREAM_WALK") ? atoi(getenv("PTGPU_STREAM_WALK")) != 0 : true;
+    static const char* env = getenv("PTGPU_STREAM_WALK");
+    static const bool on = env ? atoi(env) != 0 : true;
     return on;
 }
 void launch_extend(ptgpu_ctx* c, int grid, const PathCols& A, const HitCols& H, const RoundCounters* cnt, const uint32_t* top = nullptr) {
