@@ -2,6 +2,9 @@
 # run the GPU suite against it on the box with
 #   PTGPU_LIB=$GRAFT_REPO_ROOT/path-tracer_amd/lib/v_ubsan.so python -m pytest tests -m gpu -q -s 2>&1 | grep "runtime error"
 # (round 1: 46 tests, no reports; the oracle and libpthost were checked the same way with g++ -fsanitize=undefined).
+# Round 3: still no reports, but under this build the suite ended in hipErrorIllegalAddress at the first refinement-fuzz test behind
+# the large-soup test, three runs out of three, each costing a GPU box ("An open observation"): do not run the
+# whole suite against it on a shared pool; run single test files, and remove lib/v_ubsan.so afterwards (every gpurun call ships it).
 cd "$(dirname "$0")/.."
 R=$(ls /opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.ubsan_standalone-x86_64.so | head -1)
 /opt/rocm/bin/hipcc -O2 -g -std=c++17 --offload-arch=gfx950 -ffp-contract=off -munsafe-fp-atomics -fPIC -pthread \
